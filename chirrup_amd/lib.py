@@ -1,0 +1,72 @@
+"""Loader for libchirrup_amd.so (C ABI declared in include/chirrup_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every op
+raises.  torch is imported first on purpose -- the wheel bundles a HIP runtime with the same
+SONAME (libamdhip64.so.7) the library needs, so the process ends up with exactly one runtime
+and torch's stream handles are valid for our launches.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchirrup_amd.so")
+_lib = None
+
+E_NAMES = {-1: "CHIRRUP_E_SHAPE", -2: "CHIRRUP_E_NULL", -3: "CHIRRUP_E_ALIGN", -4: "CHIRRUP_E_UNSUPPORTED"}
+
+# name -> (restype, argtypes); mirrors include/chirrup_amd.h one to one
+_vp, _i, _i64, _f32p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+SIGNATURES = {
+    "chirrup_abi_version": (_i, []),
+    "chirrup_target_arch": (ctypes.c_char_p, []),
+    "wkv7_fwd_seq": (_i, [_i, _i, _i, _i] + [_vp] * 10 + [_i64, _vp]),
+    "wkv7_fwd_one": (_i, [_i, _i, _i] + [_vp] * 10 + [_i64, _vp]),
+    "spmv_fp16_workspace_bytes": (_i64, [_i, _i]),
+    "spmv_fp16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mm8_seq_workspace_bytes": (_i64, [_i, _i, _i]),
+    "mm8_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mm8_one": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f32p, _vp]),
+}
+
+
+class ChirrupAmdError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j4"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def load():
+    """Return the ctypes handle; raises ChirrupAmdError when the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ChirrupAmdError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or make -C chirrup_amd/csrc). There is no CPU fallback.")
+        try:
+            L = ctypes.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise ChirrupAmdError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    if rc < 0:
+        raise ChirrupAmdError(f"{what}: {E_NAMES.get(rc, rc)}")
+    raise ChirrupAmdError(f"{what}: HIP error {rc}")

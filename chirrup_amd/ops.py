@@ -1,0 +1,185 @@
+"""Operator layer (drop-in boundary B1 of SURVEY.md section 8b).
+
+Same names, argument order and in-place behaviour as the reference's
+``torch.ops.rwkv7_state_fwd_fp16.{forward_one,forward_seq,spmv_forward}``
+(Albatross/cuda/rwkv7_state_fwd_fp16.cpp:10-25) and ``torch.ops.rwkv_pip.{mm8_seq,mm8_one}``
+(scripts/test_mm8/rwkv_pip_wrapper.cpp:51-119, :206-211), implemented by the HIP kernels behind
+the C ABI (include/chirrup_amd.h).  torch tensors are only carriers of device pointers here.
+
+Differences from the reference, all on the safe side:
+  * arguments are validated (device, dtype, contiguity, shape) -- the reference only asserts
+    H*64 == C and silently mis-reads anything else;
+  * launches go to torch's CURRENT stream (the reference's forward_seq uses the null stream),
+    so the ops can be captured in a HIP graph;
+  * optional ``slot_idx`` lets a batch row address any slot of a state pool.
+"""
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+HEAD_SIZE = 64
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str, dtype, shape=None):
+    if not t.is_cuda:
+        raise _lib.ChirrupAmdError(f"{name}: expected a GPU tensor, got {t.device}")
+    if t.dtype != dtype:
+        raise _lib.ChirrupAmdError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.ChirrupAmdError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise _lib.ChirrupAmdError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+def forward_seq(B: int, T: int, C: int, H: int, state: torch.Tensor, r, w, k, v, a, b, y,
+                elapsed_t: torch.Tensor, slot_idx: Optional[torch.Tensor] = None) -> None:
+    """rwkv7_state_fwd_fp16::forward_seq (Albatross/rwkv7.py:151). Mutates ``state`` and ``y``.
+
+    state: fp16 [n_slots, H, 64, 64] (n_slots == B unless slot_idx is given); may be a
+    contiguous view into a larger pool.  r,w,k,v,a,b,y: fp16 with B*T*C elements.
+    elapsed_t: int32 [B].
+    """
+    L = _lib.load()
+    if H * HEAD_SIZE != C:
+        raise _lib.ChirrupAmdError(f"forward_seq: H*64 != C ({H}*64 != {C})")  # reference: assert, .cu:314
+    _chk(state, "state", torch.float16)
+    if state.dim() < 3 or tuple(state.shape[-3:]) != (H, HEAD_SIZE, HEAD_SIZE):
+        raise _lib.ChirrupAmdError(f"state: trailing dims must be ({H},64,64), got {tuple(state.shape)}")
+    n_slots = state.numel() // (H * HEAD_SIZE * HEAD_SIZE)
+    for name, t in (("r", r), ("w", w), ("k", k), ("v", v), ("a", a), ("b", b), ("y", y)):
+        _chk(t, name, torch.float16)
+        if t.numel() != B * T * C:
+            raise _lib.ChirrupAmdError(f"{name}: expected {B * T * C} elements, got {t.numel()}")
+    _chk(elapsed_t, "elapsed_t", torch.int32)
+    if elapsed_t.numel() != B:
+        raise _lib.ChirrupAmdError(f"elapsed_t: expected {B} elements, got {elapsed_t.numel()}")
+    si_ptr = None
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+        si_ptr = slot_idx.data_ptr()
+    elif n_slots != B:
+        raise _lib.ChirrupAmdError(f"state has {n_slots} slots for batch {B} and no slot_idx")
+    rc = L.wkv7_fwd_seq(B, T, C, H, state.data_ptr(), r.data_ptr(), w.data_ptr(), k.data_ptr(), v.data_ptr(),
+                        a.data_ptr(), b.data_ptr(), y.data_ptr(), elapsed_t.data_ptr(), si_ptr, 0, _stream())
+    _lib.check(rc, "wkv7_fwd_seq")
+
+
+def forward_one(B: int, C: int, H: int, state, r, w, k, v, a, b, y, elapsed_t,
+                slot_idx: Optional[torch.Tensor] = None) -> None:
+    """rwkv7_state_fwd_fp16::forward_one (Albatross/rwkv7.py:96,132)."""
+    forward_seq(B, 1, C, H, state, r, w, k, v, a, b, y, elapsed_t, slot_idx)
+
+
+_spmv_ws = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _spmv_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _spmv_ws[key] = ws
+    return ws
+
+
+def spmv_forward(D: int, C: int, vec: torch.Tensor, mat: torch.Tensor, out: torch.Tensor) -> None:
+    """rwkv7_state_fwd_fp16::spmv_forward (Albatross/rwkv7.py:66): out += vec @ mat, skipping
+    rows where vec is zero. ``out`` must be zeroed by the caller, as in the reference (:65)."""
+    L = _lib.load()
+    _chk(vec, "vec", torch.float16, (D,))
+    _chk(mat, "mat", torch.float16, (D, C))
+    _chk(out, "out", torch.float16, (C,))
+    ws = _workspace(L.spmv_fp16_workspace_bytes(D, C), vec.device)
+    rc = L.spmv_fp16(D, C, vec.data_ptr(), mat.data_ptr(), out.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "spmv_fp16")
+
+
+def rwkv_mm_sparsity(k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """Albatross/rwkv_mm_op_triton.py:40-61 surface: returns a new [C] tensor = k @ v."""
+    out = torch.zeros((v.size(1),), dtype=k.dtype, device=k.device)
+    spmv_forward(v.size(0), v.size(1), k, v, out)
+    return out
+
+
+def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """rwkv_pip::mm8_seq (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84): y[B,M] = x[B,N] @ dequant(w[N,M])."""
+    L = _lib.load()
+    for name, t in (("x", x), ("mx", mx), ("rx", rx), ("my", my), ("ry", ry), ("y", y)):
+        if not t.is_cuda or t.dtype != torch.float16:
+            raise _lib.ChirrupAmdError(f"{name}: expected a GPU fp16 tensor")
+    if not w.is_cuda or w.dtype != torch.uint8 or tuple(w.shape) != (N, M):
+        raise _lib.ChirrupAmdError("w: expected GPU uint8 [N,M]")
+    if tuple(x.shape) != (B, N) or tuple(y.shape) != (B, M):
+        raise _lib.ChirrupAmdError("x/y: expected [B,N] / [B,M]")
+    if x.stride(1) != 1 or w.stride(1) != 1 or y.stride(1) != 1:  # wrapper.cpp:57-59
+        raise _lib.ChirrupAmdError("x, w, y need unit inner stride")
+    if mx.numel() != M or rx.numel() != M or my.numel() != N or ry.numel() != N:
+        raise _lib.ChirrupAmdError("mx,rx need M elements and my,ry need N elements")
+    mx, rx, my, ry = (t.contiguous() for t in (mx, rx, my, ry))
+    ws = _workspace(L.mm8_seq_workspace_bytes(B, N, M), x.device)
+    rc = L.mm8_seq(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(),
+                   my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), ws.data_ptr(), _stream())
+    _lib.check(rc, "mm8_seq")
+
+
+def mm8_one(N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """rwkv_pip::mm8_one (scripts/test_mm8/rwkv_pip_wrapper.cpp:86-119): y (fp32 [M], zeroed by the
+    caller) += x[N] @ dequant(w[N,M])."""
+    L = _lib.load()
+    if not y.is_cuda or y.dtype != torch.float32 or y.numel() != M or not y.is_contiguous():
+        raise _lib.ChirrupAmdError("y: expected contiguous GPU fp32 [M]")
+    if not w.is_cuda or w.dtype != torch.uint8 or tuple(w.shape) != (N, M) or w.stride(1) != 1:
+        raise _lib.ChirrupAmdError("w: expected GPU uint8 [N,M] with unit inner stride")
+    for name, t, n in (("x", x, N), ("mx", mx, M), ("rx", rx, M), ("my", my, N), ("ry", ry, N)):
+        if not t.is_cuda or t.dtype != torch.float16 or t.numel() != n:
+            raise _lib.ChirrupAmdError(f"{name}: expected GPU fp16 with {n} elements")
+    x, mx, rx, my, ry = (t.contiguous() for t in (x, mx, rx, my, ry))
+    rc = L.mm8_one(N, M, x.data_ptr(), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(), my.data_ptr(),
+                   ry.data_ptr(), y.data_ptr(), _stream())
+    _lib.check(rc, "mm8_one")
+
+
+_registered = False
+
+
+def register_torch_ops() -> None:
+    """Register the kernels under the reference's operator names so that code written against
+    ``torch.ops.rwkv7_state_fwd_fp16.*`` / ``torch.ops.rwkv_pip.mm8_*`` runs unchanged.
+
+    If the reference's own extension already defined the namespace, only a CUDA(HIP)-key
+    implementation is added, which takes precedence over its catch-all kernel.
+    """
+    global _registered
+    if _registered:
+        return
+    T = "Tensor"
+    wkv_args = f"{T}(a!) state, {T} r, {T} w, {T} k, {T} v, {T} a, {T} b, {T}(b!) y, {T} elapsed_t"
+    schemas = {
+        "rwkv7_state_fwd_fp16": {
+            "forward_one": (f"(int B, int C, int H, {wkv_args}) -> ()", forward_one),
+            "forward_seq": (f"(int B, int T, int C, int H, {wkv_args}) -> ()", forward_seq),
+            "spmv_forward": (f"(int D, int C, {T} vec, {T} mat, {T}(a!) out) -> ()", spmv_forward),
+        },
+        "rwkv_pip": {
+            "mm8_seq": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
+            "mm8_one": (f"(int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_one),
+        },
+    }
+    keep = []
+    for ns, ops in schemas.items():
+        for name, (schema, fn) in ops.items():
+            if not hasattr(getattr(torch.ops, ns), name):
+                d = torch.library.Library(ns, "FRAGMENT")
+                d.define(name + schema)
+                keep.append(d)
+            impl = torch.library.Library(ns, "IMPL")
+            impl.impl(name, fn, "CUDA")
+            keep.append(impl)
+    register_torch_ops._keep = keep  # libraries must outlive the registration
+    _registered = True

@@ -1,0 +1,98 @@
+/*
+ * chirrup_amd.h -- C ABI of libchirrup_amd.so, the MI355X (gfx950) RWKV-7 decode kernels.
+ *
+ * This is the drop-in boundary B2 of SURVEY.md section 8(b): the entry points are what the
+ * reference's torch binding for this path calls (file:line given per function, relative to
+ * the leonsama/chirrup tree), with three additions every function shares:
+ *   - an explicit `void *stream` (a hipStream_t; NULL = the null stream),
+ *   - an `int` return: 0 on success, CHIRRUP_E_* (< 0) for arguments the kernel would
+ *     mis-handle (the reference only has `assert(H*_N_==C)`), or a positive hipError_t,
+ *   - where it shards a state pool: an optional `slot_idx` indirection.
+ * Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers.
+ * All kernels are stateless and re-entrant; they may be called concurrently from several host
+ * threads / processes, each on its own device and stream, and may be captured in a hipGraph.
+ */
+#ifndef CHIRRUP_AMD_H
+#define CHIRRUP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHIRRUP_OK 0
+#define CHIRRUP_E_SHAPE (-1)     /* C != H*64, non-positive sizes, size limits */
+#define CHIRRUP_E_NULL (-2)      /* a required pointer is NULL */
+#define CHIRRUP_E_ALIGN (-3)     /* pointer / stride not aligned as documented */
+#define CHIRRUP_E_UNSUPPORTED (-4)
+
+/* Library / ABI version and the gfx target the kernels were built for ("gfx950"). */
+int chirrup_abi_version(void);
+const char *chirrup_target_arch(void);
+
+/*
+ * WKV7 recurrent state update over T timesteps (decode: T = 1).
+ * Replaces: cuda_forward_seq  Albatross/cuda/rwkv7_state_fwd_fp16.cpp:6 (launcher
+ *           Albatross/cuda/rwkv7_state_fwd_fp16.cu:313-316, kernel :26-97), reached from
+ *           torch.ops.rwkv7_state_fwd_fp16.forward_seq (Albatross/rwkv7.py:151).
+ * state     binary16 [n_slots][H][64][64], updated in place. Batch row b uses slot
+ *           slot_idx[b] when slot_idx != NULL, else slot b. Slots are slot_stride ELEMENTS
+ *           apart (0 = dense, H*64*64). 16-byte aligned; slot_stride % 8 == 0.
+ *           Two batch rows must not name the same slot.
+ * r,w,k,v,a,b  binary16 [B][T][C] contiguous.   y  binary16 [B][T][C] out.
+ * elapsed_t int32 [B] (tokens already consumed by each row; feeds the decay dither).
+ * Arithmetic: exactly spec A1 of SURVEY.md section 8 -- binary16 storage AND binary16
+ * accumulate in the reference's two-lane order, one rounding per operation, no FMA.
+ */
+int wkv7_fwd_seq(int B, int T, int C, int H, void *state, const void *r, const void *w,
+                 const void *k, const void *v, const void *a, const void *b, void *y,
+                 const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride,
+                 void *stream);
+
+/* Single-timestep form.  Replaces: cuda_forward_one  Albatross/cuda/rwkv7_state_fwd_fp16.cpp:7
+ * (launcher .cu:318-322, kernel .cu:99-167; torch.ops.rwkv7_state_fwd_fp16.forward_one,
+ * Albatross/rwkv7.py:96,132).  r..b, y are [B][C]. Same arithmetic as wkv7_fwd_seq with T=1. */
+int wkv7_fwd_one(int B, int C, int H, void *state, const void *r, const void *w, const void *k,
+                 const void *v, const void *a, const void *b, void *y, const int32_t *elapsed_t,
+                 const int32_t *slot_idx, int64_t slot_stride, void *stream);
+
+/*
+ * Sparse binary16 vector x matrix: out[c] += sum_{d : vec[d] != 0} vec[d] * mat[d][c].
+ * Replaces: cuda_spmv_forward  Albatross/cuda/rwkv7_state_fwd_fp16.cpp:8 (launcher .cu:324-330,
+ *           kernel .cu:222-310) and the ROCm path rwkv_mm_sparsity,
+ *           Albatross/rwkv_mm_op_triton.py:6-61 (bsz = 1 channel-mix, Albatross/rwkv7.py:659).
+ * vec [D], mat [D][C] row-major, out [C]; binary16. As in the reference `out` is ACCUMULATED
+ * into, so the caller zeroes it (Albatross/rwkv7.py:65). Requires C % 8 == 0.
+ * Accumulation is binary32 in row order (the Triton path's arithmetic) and deterministic.
+ * workspace: device scratch of spmv_fp16_workspace_bytes(D, C) bytes (may be NULL if 0).
+ */
+int64_t spmv_fp16_workspace_bytes(int D, int C);
+int spmv_fp16(int D, int C, const void *vec, const void *mat, void *out, void *workspace,
+              void *stream);
+
+/*
+ * mm8 (w8a16): y[i][k] = sum_j x[i][j] * ((w[j][k] + 0.5) * rx[k] * ry[j] + mx[k] + my[j]).
+ * Replaces: rwkv_pip::mm8_seq  scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84 (kernels
+ *           scripts/test_mm8/rwkv_pip_operators.cu:59-97 and the _opt / wmma forms :205-558).
+ * x [B][N] binary16 (row stride x_stride elements), w [N][M] uint8 (row stride w_stride),
+ * mx,rx [M], my,ry [N] binary16, y [B][M] binary16 (row stride y_stride).
+ * binary32 accumulate; evaluated in the algebraically split form of
+ * scripts/test_mm8/benchmark.py:167-179 (xs = x*ry through MFMA, rank-1 corrections after).
+ * workspace: mm8_seq_workspace_bytes(B, N, M) bytes of device scratch.
+ */
+int64_t mm8_seq_workspace_bytes(int B, int N, int M);
+int mm8_seq(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+            const void *mx, const void *rx, const void *my, const void *ry, void *y,
+            int y_stride, void *workspace, void *stream);
+
+/* GEMV form, binary32 output that the caller zeroes (the reference accumulates with
+ * atomicAdd).  Replaces: rwkv_pip::mm8_one  scripts/test_mm8/rwkv_pip_wrapper.cpp:86-119
+ * (kernel scripts/test_mm8/rwkv_pip_operators.cu:150-189). x [N], y [M] float. */
+int mm8_one(int N, int M, const void *x, const void *w, int w_stride, const void *mx,
+            const void *rx, const void *my, const void *ry, float *y, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHIRRUP_AMD_H */
