@@ -68,13 +68,15 @@ def test_spmv_vs_oracle(oracle, D, C, density):
     got = out.cpu().numpy()
     ulp = np.abs(bits(got).astype(np.int32) - bits(want).astype(np.int32))
     same_sign = (bits(got) & 0x8000) == (bits(want) & 0x8000)
-    big = (np.abs(want) > 1e-3) & same_sign
+    scale = float(np.abs(want.astype(np.float32)).max()) if want.size else 0.0
+    big = (np.abs(want.astype(np.float32)) > 0.05 * scale) & same_sign & (scale > 0)
     assert ulp[big].max(initial=0) <= 1
     assert (ulp[big] == 1).mean() < 0.02 if big.any() else True
-    assert np.allclose(got.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=1e-4)
+    # outputs that nearly cancel are only as good as binary32 accumulation of ~D terms
+    assert np.allclose(got.astype(np.float32), want.astype(np.float32), rtol=1e-3, atol=1e-3 * scale + 1e-7)
     # accumulate semantics: a second call adds again
     ops.spmv_forward(D, C, torch.from_numpy(vec).cuda(), torch.from_numpy(mat).cuda(), out)
-    assert np.allclose(out.cpu().numpy().astype(np.float32), 2 * want.astype(np.float32), rtol=4e-3, atol=2e-4)
+    assert np.allclose(out.cpu().numpy().astype(np.float32), 2 * want.astype(np.float32), rtol=4e-3, atol=2e-3 * scale + 1e-7)
     # Triton-surface wrapper returns a fresh tensor
     z = ops.rwkv_mm_sparsity(torch.from_numpy(vec).cuda(), torch.from_numpy(mat).cuda())
     assert np.array_equal(bits(z.cpu().numpy()), bits(got))

@@ -94,7 +94,7 @@ def test_wkv7_view_into_layer_pool(oracle):
     rng = np.random.default_rng(9)
     pool = (rng.standard_normal((L_, n, H, 64, 64)) * 0.5).astype(np.float16)
     _, r, w, k, v, a, b, et = wkv7_inputs(3, 1, C, seed=10)
-    S_ref = np.ascontiguousarray(pool[1, 2:5])
+    S_ref = pool[1, 2:5].copy()
     y_ref = oracle.wkv7_seq(S_ref, r, w, k, v, a, b, et)
     t_pool = torch.from_numpy(pool.copy()).cuda()
     tr, tw, tk, tv, ta, tb = (torch.from_numpy(x).cuda() for x in (r, w, k, v, a, b))
