@@ -1,0 +1,218 @@
+"""bench.py -- decode throughput of the RWKV-7 hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model 7.2B] [--bsz 200]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one decode step of the whole model for one batch of B requests per GPU: embedding
+gather -> L x (time-mix incl. the WKV7 state update, channel-mix) -> head GEMM -> greedy sample ->
+token ids on the host (what the worker needs every iteration, chirrup/worker.py:704-740).
+Weights, states and inputs are resident in HBM before the timed region.  Multi-GPU = the
+reference's only parallelism: independent replicas, one process per GPU, a
+batch of B per GPU, no data-path collective ("scaling": "weak").
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     -- the WKV7 kernel: algorithmic bytes B*(270*C+4) per launch / HIP-event launch time
+  cpu_baseline -- the CPU oracle (port of the reference arithmetic) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--warmup", type=int, default=8)
+    p.add_argument("--model", default="7.2B")
+    p.add_argument("--bsz", type=int, default=200)
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-layers", type=int, default=2, help="layers of the model the CPU baseline times")
+    return p.parse_args()
+
+
+def build_model(name, device, fused):
+    from chirrup_amd.rwkv7 import RWKV_x070, model_args
+    from chirrup_amd.synth import CONFIGS, make_state_dict
+
+    L, C = CONFIGS[name]
+    zd = make_state_dict(L, C, 65536, seed=42, device=device)      # random-init weights of the architecture
+    m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused)
+    del zd
+    torch.cuda.empty_cache()
+    return m
+
+
+def make_state(model, B, seed=1234):
+    g = torch.Generator(device=model.device)
+    g.manual_seed(seed)
+    st = model.generate_zero_state(B)
+    st[0].copy_((torch.randn(st[0].shape, generator=g, device=model.device) * 0.5).half())
+    st[1].copy_((torch.randn(st[1].shape, generator=g, device=model.device) * 0.1).half())
+    st[2].copy_(torch.arange(B, device=model.device, dtype=torch.int32) * 7 + 3)
+    return st
+
+
+def wkv7_event_timing(model, state, B, iters=3):
+    """Average WKV7 launch duration (ms), HIP events on the launch stream, rotating over the
+    model's L per-layer states (L*B*H*8 KiB >> Infinity Cache) with real-shaped inputs."""
+    from chirrup_amd import ops
+
+    C, H, L = model.n_embd, model.n_head, model.n_layer
+    dev = model.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    mk = lambda s: (torch.randn((B, 1, C), generator=g, device=dev) * s).half()
+    r, k, v = mk(1.0), mk(1.0), mk(1.0)
+    w = (torch.rand((B, 1, C), generator=g, device=dev) * 12 - 8).half()
+    a, b = mk(0.125), mk(0.06)
+    y = torch.empty((B, 1, C), dtype=torch.float16, device=dev)
+    snap = state[1].clone()
+    evs = []
+    for _ in range(iters):
+        for layer in range(L):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.forward_seq(B, 1, C, H, state[1][layer], r, w, k, v, a, b, y, state[2])
+            e1.record()
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    state[1].copy_(snap)
+    ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs[L:])     # first pass = warm-up
+    return sum(ms) / len(ms)
+
+
+def cpu_baseline(name, B, n_layers):
+    """The CPU oracle (numpy + C restatement of the reference arithmetic, kind "port") on the host
+    cores: `n_layers` layers of the model at the bench batch size + the head GEMM, scaled to L."""
+    import numpy as np
+
+    from chirrup_amd.synth import CONFIGS, make_state_dict
+    from oracle import native
+    from oracle import rwkv7_np as M
+
+    native.build()
+    L, C = CONFIGS[name]
+    V = 65536
+    torch.manual_seed(0)
+    zd = make_state_dict(n_layers, C, V, seed=42)
+    z = M.prepare_weights({k_: t.numpy() for k_, t in zd.items()})
+    del zd
+    rng = np.random.default_rng(1234)
+    toks = rng.integers(1, V, size=(B, 1)).tolist()
+    st = [(rng.standard_normal((n_layers, 2, B, C)) * 0.5).astype(np.float16),
+          (rng.standard_normal((n_layers, B, C // 64, 64, 64)) * 0.1).astype(np.float16),
+          (np.arange(B) * 7 + 3).astype(np.int32)]
+    t0 = time.perf_counter()
+    M.forward_seq_batch(z, toks, st, n_layer=0)                      # embedding + ln_out + head only
+    t_head = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    M.forward_seq_batch(z, toks, st, n_layer=n_layers)
+    t_all = time.perf_counter() - t0
+    t_layer = max(t_all - t_head, 1e-9) / n_layers
+    step = t_layer * L + t_head
+    return {"value": round(B / step, 2), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_layers} of {L} layers + head of RWKV7 {name} at bsz {B} (oracle/rwkv7_np.py + oracle.c), "
+                      f"{t_all:.1f}s measured, scaled to {L} layers"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback in the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from chirrup_amd.synth import CONFIGS
+
+    L, C = CONFIGS[a.model]
+    B = a.bsz
+    model = build_model(a.model, dev, fused=not a.no_fused)
+    state = make_state(model, B)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    tokens = torch.randint(1, 65536, (B, 1), generator=g, device=dev)
+    ids_host = torch.empty((B,), dtype=torch.long).pin_memory()
+
+    if a.no_graph:
+        step_fn = lambda tok: model.forward_seq_batch(tok, state)
+    else:
+        graph = model.capture_decode_graph(state)
+        step_fn = graph.step
+
+    def one_step(tok):
+        logits = step_fn(tok)
+        nxt = logits.argmax(dim=-1)                 # greedy: temperature 0 (samplers.py:195-197)
+        ids_host.copy_(nxt, non_blocking=False)     # the worker needs the ids on the host each step
+        return nxt.view(B, 1)
+
+    for _ in range(a.warmup):
+        tokens = one_step(tokens)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tokens = one_step(tokens)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    wkv_ms = wkv7_event_timing(model, state, B)
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        bytes_per_launch = B * (270 * C + 4)
+        achieved = bytes_per_launch / (wkv_ms * 1e-3) / 1e9
+        weight_bytes = sum(t.numel() * t.element_size() for n, t in model.z.items() if n != "emb.weight")
+        step_bytes = weight_bytes + L * bytes_per_launch + B * 65536 * 2
+        out = {
+            "metric": "decode tokens/sec (whole job) and tps/request, RWKV7-g1 " + a.model + f" bsz={B}/GPU",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "tps_per_request": round(1e3 / ms_per_step, 2),
+            "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
+                                   "greedy decode step incl. sampling and token-id D2H; random-init weights",
+                       "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
+                       "graph": not a.no_graph, "fused_elementwise": not a.no_fused},
+            "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "bytes_per_launch": bytes_per_launch, "launch_us": round(wkv_ms * 1e3, 2),
+                         "launches_per_step": L},
+            "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.model, B, a.cpu_layers)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,319 @@
+"""Host-side model for the RWKV-7 decode hot path: drop-in boundary B3.
+
+Mirrors the surface chirrup's worker uses from ``Albatross.rwkv7.RWKV_x070`` (chirrup/worker.py:18,
+:212-220, :260, :588, :704, :775):
+
+    model = RWKV_x070(args)                       # args.MODEL_NAME (no ".pth"), vocab_size, head_size
+    state = model.generate_zero_state(n)          # [fp16[L,2,n,C], fp16[L,n,H,64,64], int32[n]]
+    logits = model.forward_seq_batch_seperate(tokens, state_views)   # fp16 [B,V], state mutated
+
+plus ``forward / forward_batch / forward_seq_batch / forward_one / forward_seq``, ``.z`` and
+``get_gpu_parameter_groups()`` with the same meaning.  It is NOT a copy of the reference's
+TorchScript module: the per-layer work is organised around the HIP kernels of this package
+
+    LN1 + token-shift + 6 lerps   ->  one fused kernel          (csrc/elementwise.hip)
+    R/K/V/O, LoRA, FFN, head      ->  hipBLASLt through torch.matmul (plain library GEMMs)
+    k/kk/a/v gating chain         ->  one fused kernel
+    WKV7 state update             ->  csrc/wkv7.hip (bit-exact spec A1)
+    group-norm + bonus + gate     ->  one fused kernel
+    LN2 + token-shift + lerp, relu^2  ->  fused kernels
+
+and the whole decode step can be captured in a HIP graph (`capture_decode_graph`).  With
+``fused=False`` the same arithmetic runs as plain torch ops (one rounding to fp16 per op, exactly
+the reference's eager semantics); that path exists for parity tests and for CPU host-logic tests
+and still calls the HIP WKV7 kernel on GPU -- there is no CPU fallback in the product.
+"""
+import types
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+HEAD_SIZE = 64
+DTYPE = torch.float16
+
+_T_KEYS = ("att.g1", "att.g2", "att.a1", "att.a2", "att.w1", "att.w2", "att.v1", "att.v2", "ffn.value.weight")
+
+
+def convert_checkpoint(z_disk: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    """Checkpoint layout -> runtime layout.  Same result as the reference's load
+    (Albatross/rwkv7.py:211-221: transpose the LoRA pairs and ffn.value, squeeze, fp16, flatten
+    r_k; :206 emb <- LN0(emb))."""
+    z: Dict[str, torch.Tensor] = {}
+    for name, t in z_disk.items():
+        if any(s in name for s in _T_KEYS):
+            t = t.t()
+        t = t.squeeze().to(dtype=DTYPE, device=device)
+        if name.endswith("att.r_k"):
+            t = t.flatten()
+        z[name] = t.contiguous()
+    C = z["emb.weight"].shape[1]
+    emb = z["emb.weight"]
+    # chunked so a 65536 x 4096 table never needs a second full-size fp32 copy
+    for lo in range(0, emb.shape[0], 8192):
+        sl = slice(lo, lo + 8192)
+        emb[sl] = F.layer_norm(emb[sl].float(), (C,), weight=z["blocks.0.ln0.weight"].float(),
+                               bias=z["blocks.0.ln0.bias"].float()).to(DTYPE)
+    # layer 0 has no value-residual gate; the reference aliases its unused v* to a* (:207-209)
+    for s in ("0", "1", "2"):
+        z["blocks.0.att.v" + s] = z["blocks.0.att.a" + s]
+    return z
+
+
+class _Layer:
+    """Per-layer weight views, resolved once so the hot loop does no dict lookups."""
+
+    __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
+                 "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
+                 "f_K", "f_V", "mix6")
+
+    def __init__(self, z, i):
+        b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
+        self.ln1_w, self.ln1_b = z[b + "ln1.weight"], z[b + "ln1.bias"]
+        self.ln2_w, self.ln2_b = z[b + "ln2.weight"], z[b + "ln2.bias"]
+        for n in ("x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1", "a2", "v0", "v1", "v2", "g1", "g2",
+                  "k_k", "k_a", "r_k"):
+            setattr(self, n, z[a + n])
+        self.R, self.K, self.V, self.O = (z[a + n + ".weight"] for n in ("receptance", "key", "value", "output"))
+        self.lnx_w, self.lnx_b = z[a + "ln_x.weight"], z[a + "ln_x.bias"]
+        self.f_x_k, self.f_K, self.f_V = z[f + "x_k"], z[f + "key.weight"], z[f + "value.weight"]
+        self.mix6 = None
+
+
+class RWKV_x070:
+    """See module docstring.  ``wkv_impl`` is a test hook (signature of ops.forward_seq); the
+    default is the HIP kernel and nothing else is ever selected automatically."""
+
+    def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
+                 fused: bool = True, wkv_impl: Optional[Callable] = None):
+        self.args = args
+        args.head_size = HEAD_SIZE
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        if state_dict is None:
+            state_dict = torch.load(args.MODEL_NAME + ".pth", map_location="cpu")   # rwkv7.py:171
+        self.n_head, self.head_size = state_dict["blocks.0.att.r_k"].shape
+        assert self.head_size == HEAD_SIZE == args.head_size
+        args.n_embd = self.n_head * self.head_size
+        args.n_layer = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
+        self.n_layer, self.n_embd = args.n_layer, args.n_embd
+        self.z = convert_checkpoint(state_dict, self.device) if auto_load else dict(state_dict)
+        self.fused = fused and self.device.type == "cuda"
+        self._wkv = wkv_impl if wkv_impl is not None else ops.forward_seq
+        self._layers = [_Layer(self.z, i) for i in range(self.n_layer)] if auto_load else []
+
+    # ------------------------------------------------------------------ reference surface
+    def generate_zero_state(self, bsz: int):
+        """Albatross/rwkv7.py:224-235."""
+        L, C, H, N = self.n_layer, self.n_embd, self.n_head, self.head_size
+        dev = self.device
+        if bsz >= 1:
+            return [torch.zeros((L, 2, bsz, C), dtype=DTYPE, device=dev),
+                    torch.zeros((L, bsz, H, N, N), dtype=DTYPE, device=dev),
+                    torch.zeros((bsz,), dtype=torch.int32, device=dev)]
+        return [torch.zeros((L, 2, C), dtype=DTYPE, device=dev), torch.zeros((L, H, N, N), dtype=DTYPE, device=dev),
+                torch.zeros((), dtype=torch.int32, device=dev)]
+
+    def get_gpu_parameter_groups(self, print_details: bool = False):
+        """[{size, keys}] for pre / each layer / post (Albatross/rwkv7.py:384-500)."""
+        z = self.z
+        nbytes = lambda keys: sum(z[k].numel() * z[k].element_size() for k in keys)
+        groups = []
+        pre = ["emb.weight", "blocks.0.ln0.weight", "blocks.0.ln0.bias"]
+        groups.append({"size": nbytes(pre), "keys": pre})
+        att_names = ["x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1", "a2", "v0", "v1", "v2", "g1", "g2",
+                     "k_k", "k_a", "r_k", "receptance.weight", "key.weight", "value.weight", "output.weight",
+                     "ln_x.weight", "ln_x.bias"]
+        for i in range(self.n_layer):
+            b = f"blocks.{i}."
+            keys = [b + "ln1.weight", b + "ln1.bias"] + [b + "att." + n for n in att_names] + \
+                   [b + "ln2.weight", b + "ln2.bias"] + [b + "ffn." + n for n in ("x_k", "key.weight", "value.weight")]
+            groups.append({"size": nbytes(keys), "keys": keys})
+        post = ["ln_out.weight", "ln_out.bias", "head.weight"]
+        groups.append({"size": nbytes(post), "keys": post})
+        if print_details:
+            for g in groups:
+                print(f"{g['size'] / 2**20:.2f} MB: {g['keys'][0]} ... ({len(g['keys'])} tensors)")
+        return groups
+
+    def forward(self, idx, state, full_output=False):
+        """Albatross/rwkv7.py:237-248: a token, a list of tokens, or an embedding row."""
+        if isinstance(idx, list):
+            if len(idx) > 1:
+                return self.forward_seq(idx, state, full_output)
+            return self.forward_one(self.z["emb.weight"][idx[0]], state)
+        if isinstance(idx, torch.Tensor):
+            return self.forward_one(idx, state)
+        return self.forward_one(self.z["emb.weight"][idx], state)
+
+    def forward_one(self, x: torch.Tensor, state):
+        """bsz-less single token (state tensors without a batch dim), rwkv7.py:287-316."""
+        st = [state[0].unsqueeze(2), state[1].unsqueeze(1), state[2].reshape(1)]
+        out = self._forward_embedded(x.reshape(1, 1, -1), st, 1, False)
+        state[2] += 1
+        return out.reshape(-1)
+
+    def forward_seq(self, idx: List[int], state, full_output: bool = False):
+        """rwkv7.py:318-349."""
+        st = [state[0].unsqueeze(2), state[1].unsqueeze(1), state[2].reshape(1)]
+        out = self._forward_tokens([idx], st, full_output)
+        state[2] += len(idx)
+        return out[0]
+
+    def forward_batch(self, tokens, state, full_output=False):
+        """Ragged batches: repeatedly advance every unfinished row by the shortest remaining
+        length (rwkv7.py:250-280)."""
+        lengths = [len(t) for t in tokens]
+        if len(set(lengths)) == 1 and not full_output:
+            return self.forward_seq_batch(tokens, state, full_output)
+        bsz = len(tokens)
+        pos = [0] * bsz
+        out = [None] * bsz if full_output else torch.empty((bsz, self.args.vocab_size), dtype=DTYPE, device=self.device)
+        while True:
+            active = [i for i in range(bsz) if pos[i] < lengths[i]]
+            if not active:
+                return out
+            step = min(lengths[i] - pos[i] for i in active)
+            sub = [state[0][:, :, active], state[1][:, active], state[2][active]]     # gathers (copies)
+            res = self.forward_seq_batch([tokens[i][pos[i]:pos[i] + step] for i in active], sub, full_output)
+            for j, i in enumerate(active):
+                if full_output:
+                    out[i] = res[j] if out[i] is None else torch.cat([out[i], res[j]], dim=0)
+                else:
+                    out[i] = res[j]
+                state[0][:, :, i] = sub[0][:, :, j]
+                state[1][:, i] = sub[1][:, j]
+                state[2][i] = sub[2][j]
+                pos[i] += step
+
+    def forward_batch_same_length(self, tokens, state, full_output=False):
+        assert len(set(len(x) for x in tokens)) == 1, "here all sequences must have the same length"
+        return self.forward_seq_batch(tokens, state, full_output)
+
+    def forward_seq_batch(self, idxs: Sequence[Sequence[int]], state, full_output: bool = False):
+        """rwkv7.py:351-382."""
+        out = self._forward_tokens(idxs, state, full_output)
+        state[2] += len(idxs[0])
+        return out
+
+    def forward_seq_batch_seperate(self, idxs, state, full_output: bool = False):
+        """The entry point the worker calls (chirrup/worker.py:704, :775; rwkv7.py:555-563)."""
+        return self.forward_seq_batch(idxs, state, full_output)
+
+    # ------------------------------------------------------------------ implementation
+    def _forward_tokens(self, idxs, state, full_output):
+        if isinstance(idxs, torch.Tensor):          # [B,T] int64 already on the device (graph path)
+            tok = idxs
+        else:
+            lens = {len(t) for t in idxs}
+            assert len(lens) == 1, "here all sequences must have the same length"   # rwkv7.py:284
+            tok = torch.tensor(idxs, device=self.device, dtype=torch.long)
+        x = self.z["emb.weight"][tok]                                            # [B,T,C]
+        return self._forward_embedded(x, state, tok.shape[1], full_output)
+
+    def capture_decode_graph(self, state, warmup: int = 2):
+        """Capture ONE decode step (T=1) over the given state views in a HIP graph.
+
+        Returns a DecodeGraph; ``g.step(tokens)`` copies B token ids into the static input, replays
+        the graph (embedding gather ... head GEMM, state and elapsed_t updated in place) and
+        returns the static fp16 [B,V] logits tensor.  The state views must stay where they are
+        (they do: the worker's slot table is preallocated, chirrup/worker.py:260)."""
+        return DecodeGraph(self, state, warmup)
+
+    def _forward_embedded(self, x, state, T, full_output):
+        z = self.z
+        s0, s1, s2 = state
+        v_first = None
+        for i, lw in enumerate(self._layers):
+            xx = F.layer_norm(x, (self.n_embd,), weight=lw.ln1_w, bias=lw.ln1_b)
+            xx, v_first = self._tmix(i, lw, xx, s0[i], v_first, s1[i], s2)
+            x = x + xx
+            xx = F.layer_norm(x, (self.n_embd,), weight=lw.ln2_w, bias=lw.ln2_b)
+            x = x + self._cmix(lw, xx, s0[i])
+        if not full_output:
+            x = x[:, -1, :]
+        x = F.layer_norm(x, (self.n_embd,), weight=z["ln_out.weight"], bias=z["ln_out.bias"])
+        return F.linear(x, z["head.weight"])
+
+    def _tmix(self, layer_id, lw: _Layer, x, x_prev, v_first, S, elapsed_t):
+        """Time-mix block, arithmetic of RWKV_x070_TMix_seq_batch (rwkv7.py:618-649).
+        x [B,T,C] (already LN1'd); x_prev = state[0][layer] ([2,B,C]); S = state[1][layer]."""
+        B, T, C = x.shape
+        H, N = self.n_head, self.head_size
+        dx = torch.cat((x_prev[0].unsqueeze(1), x[:, :-1, :]), dim=1) - x
+        x_prev[0] = x[:, -1, :]
+        xr, xw, xk, xv, xa, xg = (x + dx * m for m in (lw.x_r, lw.x_w, lw.x_k, lw.x_v, lw.x_a, lw.x_g))
+        r = F.linear(xr, lw.R)
+        w = F.linear(torch.tanh(F.linear(xw, lw.w1)), lw.w2, bias=lw.w0)
+        k = F.linear(xk, lw.K)
+        v = F.linear(xv, lw.V)
+        a = torch.sigmoid(F.linear(F.linear(xa, lw.a1), lw.a2, bias=lw.a0))
+        g = F.linear(torch.sigmoid(F.linear(xg, lw.g1)), lw.g2)
+        kk = F.normalize((k * lw.k_k).view(B, T, H, N), dim=-1, p=2.0).view(B, T, C)
+        k = k * (1 + (a - 1) * lw.k_a)
+        kka = kk * a
+        if layer_id == 0:
+            v_first = v
+        else:
+            v = v + (v_first - v) * torch.sigmoid(F.linear(F.linear(xv, lw.v1), lw.v2, bias=lw.v0))
+        y = torch.empty((B, T, C), dtype=DTYPE, device=x.device)
+        if not S.is_contiguous():
+            raise ops._lib.ChirrupAmdError("state[1][layer] view must be contiguous (slice the batch dim only)")
+        self._wkv(B, T, C, H, S, r.contiguous(), w.contiguous(), k.contiguous(), v.contiguous(),
+                  (-kk).contiguous(), kka.contiguous(), y, elapsed_t)
+        y = F.group_norm(y.view(B * T, C), num_groups=H, weight=lw.lnx_w, bias=lw.lnx_b, eps=64e-5).view(B, T, C)
+        y = y + ((r * k * lw.r_k).view(B, T, H, N).sum(dim=-1, keepdim=True) * v.view(B, T, H, N)).view(B, T, C)
+        return F.linear(y * g, lw.O), v_first
+
+    def _cmix(self, lw: _Layer, x, x_prev):
+        """Channel-mix block, arithmetic of RWKV_x070_CMix_seq_batch (rwkv7.py:673-679)."""
+        dx = torch.cat((x_prev[1].unsqueeze(1), x[:, :-1, :]), dim=1) - x
+        x_prev[1] = x[:, -1, :]
+        k = x + dx * lw.f_x_k
+        k = torch.relu(F.linear(k, lw.f_K)) ** 2
+        return k @ lw.f_V
+
+
+class DecodeGraph:
+    """HIP-graph replay of the decode step: removes the per-kernel host launch cost (the
+    reference spends ~1300 launches per step at L=32, SURVEY.md section 7 "Launch overhead")."""
+
+    def __init__(self, model: RWKV_x070, state, warmup: int = 2):
+        assert model.device.type == "cuda"
+        self.model, self.state = model, state
+        B = state[2].shape[0]
+        self.B = B
+        self.tokens = torch.zeros((B, 1), dtype=torch.long, device=model.device)
+        snap = [t.clone() for t in state]                 # warm-up must not advance the real state
+        side = torch.cuda.Stream(device=model.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                model.forward_seq_batch(self.tokens, state)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = model.forward_seq_batch(self.tokens, state)
+        torch.cuda.synchronize()
+        for t, s in zip(state, snap):
+            t.copy_(s)
+
+    def step(self, tokens) -> torch.Tensor:
+        if isinstance(tokens, torch.Tensor):
+            self.tokens.copy_(tokens.reshape(self.B, 1), non_blocking=True)
+        else:
+            self.tokens.copy_(torch.tensor(tokens, dtype=torch.long).reshape(self.B, 1), non_blocking=True)
+        self.graph.replay()
+        return self.logits
+
+
+def model_args(model_path: str, vocab_size: int = 65536, head_size: int = 64):
+    """The namespace the worker builds (chirrup/worker.py:212-218)."""
+    a = types.SimpleNamespace()
+    a.vocab_size, a.head_size = vocab_size, head_size
+    a.MODEL_NAME = model_path[:-4] if model_path.endswith(".pth") else model_path
+    return a

@@ -1,0 +1,105 @@
+"""GPU parity of the whole decode / chunked-prefill step (boundary B3) against the golden fixtures
+(outputs of the reference's own Python on CPU) and the numpy oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import bits
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+F32 = np.float32
+
+
+def rel_linf(got, want):
+    w = want.astype(F32)
+    return float(np.abs(got.astype(F32) - w).max() / max(1.0, float(np.abs(w).max())))
+
+
+def _model(fused):
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    args = types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
+    return d, RWKV_x070(args, state_dict=zd, device="cuda:0", fused=fused)
+
+
+@pytest.fixture(scope="module", params=[False, True], ids=["torch_ops", "fused"])
+def setup(request):
+    return _model(request.param)
+
+
+@pytest.mark.parametrize("tag", ["b1t1", "b3t1", "b3t5", "b1t5"])
+def test_forward_vs_reference_fixture(setup, tag):
+    """north_star: state within 1e-3 (relative to the tensor's magnitude, see tests/test_golden_cpu.py),
+    logits within 2e-3 the same way; elapsed_t exact."""
+    d, m = setup
+    st = [torch.from_numpy(d[f"{tag}:{n}_in"].copy()).cuda() for n in ("s0", "s1", "s2")]
+    lg = m.forward_seq_batch_seperate(d[f"{tag}:tokens"].tolist(), st)
+    assert np.array_equal(st[2].cpu().numpy(), d[f"{tag}:s2_out"])
+    assert rel_linf(st[0].cpu().numpy(), d[f"{tag}:s0_out"]) <= 1.5e-3
+    assert rel_linf(st[1].cpu().numpy(), d[f"{tag}:s1_out"]) <= 1e-3
+    assert rel_linf(lg.cpu().numpy(), d[f"{tag}:logits"]) <= 2e-3
+
+
+def test_greedy_token_ids_bit_exact(setup):
+    d, m = setup
+    st = m.generate_zero_state(2)
+    lg = m.forward_seq_batch_seperate(d["greedy:prompt"].tolist(), st)
+    ids = []
+    for s in range(d["greedy:ids"].shape[1]):
+        assert rel_linf(lg.cpu().numpy(), d["greedy:step_logits"][:, s]) <= 3e-3
+        nxt = lg.float().argmax(dim=-1)
+        ids.append(nxt.cpu().numpy())
+        lg = m.forward_seq_batch_seperate([[int(t)] for t in nxt.tolist()], st)
+    assert np.array_equal(np.stack(ids, 1), d["greedy:ids"])
+    assert np.array_equal(st[2].cpu().numpy(), d["greedy:s2_final"])
+    assert rel_linf(st[1].cpu().numpy(), d["greedy:s1_final"]) <= 3e-3
+
+
+def test_graph_replay_equals_eager(setup):
+    """The HIP-graph decode step gives bit-identical logits and state to the eager step."""
+    d, m = setup
+    B = 3
+    tag = "b3t1"
+    ste = [torch.from_numpy(d[f"{tag}:{n}_in"].copy()).cuda() for n in ("s0", "s1", "s2")]
+    stg = [t.clone() for t in ste]
+    g = m.capture_decode_graph(stg)
+    assert all(torch.equal(a, b) for a, b in zip(ste, stg))      # capture left the state untouched
+    toks = d[f"{tag}:tokens"].tolist()
+    for _ in range(3):
+        le = m.forward_seq_batch_seperate(toks, ste)
+        lgr = g.step(toks).clone()
+        assert torch.equal(le, lgr)
+        toks = [[int(t)] for t in le.float().argmax(-1).tolist()]
+    assert all(torch.equal(a, b) for a, b in zip(ste, stg))
+    assert stg[2].tolist() == [6, 13, 20]
+
+
+def test_larger_config_vs_numpy_oracle(oracle):
+    """0.1B-shaped layer stack (C=768, H=12, 3 layers, real LoRA ranks), bsz 4, prefill 6 + 2 decode
+    steps, against the numpy restatement run on the same synthetic weights."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from chirrup_amd.synth import make_state_dict
+    from oracle import rwkv7_np as M
+
+    L, C, V, B = 3, 768, 1024, 4
+    zd = make_state_dict(L, C, V, seed=7, varied_norms=True)
+    z_np = M.prepare_weights({k: v.numpy() for k, v in zd.items()})
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(1, V, size=(B, 6)).tolist()
+    st_np = [np.zeros((L, 2, B, C), np.float16), np.zeros((L, B, C // 64, 64, 64), np.float16), np.zeros((B,), np.int32)]
+    lg_np = M.forward_seq_batch(z_np, prompt, st_np, n_layer=L)
+    for fused in (False, True):
+        m = RWKV_x070(types.SimpleNamespace(vocab_size=V, head_size=64, MODEL_NAME="unused"), state_dict=zd,
+                      device="cuda:0", fused=fused)
+        st = m.generate_zero_state(B)
+        lg = m.forward_seq_batch_seperate(prompt, st)
+        assert rel_linf(lg.cpu().numpy(), lg_np) <= 3e-3
+        assert rel_linf(st[1].cpu().numpy(), st_np[1]) <= 1e-3
+        assert rel_linf(st[0].cpu().numpy(), st_np[0]) <= 2e-3
+        assert st[2].tolist() == [6] * B
