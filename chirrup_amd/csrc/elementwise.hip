@@ -1,0 +1,350 @@
+// Fused element-wise / normalisation kernels around the WKV7 update and the projection GEMMs.
+//
+// The reference runs this work as ~40 separate torch kernels per layer (SURVEY.md section 8a, A4/A5:
+// "launch-bound").  Here each chain between two GEMMs is ONE kernel.  Arithmetic keeps the
+// reference's eager semantics: every torch op of the chain rounds to binary16 once, reductions
+// (layer-norm, group-norm, L2 norm, head sums) accumulate in binary32 and round once -- so results
+// match the unfused torch-op path except for the summation order inside a reduction.
+//
+//   add_ln_mix   x_new = x (+ delta);  cur = LN(x_new);  dx = prev - cur;  out[m] = cur + dx*mix[m]
+//                (rwkv7.py:523 + :621-623 with 6 mix vectors; :533 + :675-677 with 1; :548-550 with 0)
+//   tmix_mid     a = sigmoid(.), kk = normalize(k*k_k) per head, k *= 1+(a-1)*k_a, kka = kk*a,
+//                v += (v_first - v)*sigmoid(.)                        (rwkv7.py:629-637)
+//   tmix_post    group_norm(y) + (sum_head r*k*r_k)*v, times g         (rwkv7.py:647-649)
+//   relu_sq      relu(k)**2                                             (rwkv7.py:678)
+//
+// Layout: rows of C binary16 channels, 16-byte (8-channel) accesses per lane everywhere; a 64-wide
+// head is 8 consecutive lanes, so head reductions are 3 DPP/shuffle steps inside a wavefront.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chirrup_amd.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f16 h(float x) { return (f16)x; }                // one rounding to binary16
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float head_sum(float v) {   // 8 consecutive lanes = one 64-channel head
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+constexpr int kLnThreads = 256;
+constexpr int kLnMaxChunks = 4;   // 256 lanes x 4 chunks x 8 channels -> C <= 8192
+
+__device__ __forceinline__ float block_sum(float v, float *red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnThreads / 64; i++) t += red[i];
+    return t;
+}
+
+// Load row (x + delta) as binary16, return its layer-norm in `out` (binary16 values held as float).
+// If x_out != nullptr the summed row is stored there.
+__device__ __forceinline__ void ln_row(const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
+                                       const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
+                                       float (&out)[kLnMaxChunks][8], float *red) {
+    const int nchunk = C >> 3;
+    float vals[kLnMaxChunks][8];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < kLnMaxChunks; q++) {
+        const int c = threadIdx.x + q * kLnThreads;
+        if (c < nchunk) {
+            f16x8 xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
+            if (delta) {
+                const f16x8 dv = *reinterpret_cast<const f16x8 *>(delta + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)dv[e]);
+            }
+            if (x_out) *reinterpret_cast<f16x8 *>(x_out + c * 8) = xv;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                vals[q][e] = (float)xv[e];
+                s += vals[q][e];
+            }
+        }
+    }
+    const float mean = block_sum(s, red) / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < kLnMaxChunks; q++) {
+        const int c = threadIdx.x + q * kLnThreads;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float d = vals[q][e] - mean;
+                s2 += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(s2, red) / (float)C + eps);
+#pragma unroll
+    for (int q = 0; q < kLnMaxChunks; q++) {
+        const int c = threadIdx.x + q * kLnThreads;
+        if (c < nchunk) {
+            const f16x8 wv = *reinterpret_cast<const f16x8 *>(w + c * 8);
+            const f16x8 bv = *reinterpret_cast<const f16x8 *>(b + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) out[q][e] = (float)h((vals[q][e] - mean) * rstd * (float)wv[e] + (float)bv[e]);
+        }
+    }
+}
+
+// One workgroup per (b, t) row.
+template <int NMIX>
+__global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
+    const int T, const int C, const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
+    const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
+    f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride) {
+    __shared__ float red[kLnThreads / 64];
+    const int row = blockIdx.x;
+    const int bb = row / T, t = row - bb * T;
+    const int nchunk = C >> 3;
+    const int64_t ro = (int64_t)row * C;
+    float cur[kLnMaxChunks][8];
+    ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red);
+    if (NMIX == 0) {
+#pragma unroll
+        for (int q = 0; q < kLnMaxChunks; q++) {
+            const int c = threadIdx.x + q * kLnThreads;
+            if (c < nchunk) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = h(cur[q][e]);
+                *reinterpret_cast<f16x8 *>(out + ro + c * 8) = o;
+            }
+        }
+        return;
+    }
+    // token shift: previous row's LN (recomputed) or the carried state for t == 0
+    float prev[kLnMaxChunks][8];
+    if (t == 0) {
+#pragma unroll
+        for (int q = 0; q < kLnMaxChunks; q++) {
+            const int c = threadIdx.x + q * kLnThreads;
+            if (c < nchunk) {
+                const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + (int64_t)bb * C + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) prev[q][e] = (float)pv[e];
+            }
+        }
+    } else {
+        ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red);
+    }
+#pragma unroll
+    for (int q = 0; q < kLnMaxChunks; q++) {
+        const int c = threadIdx.x + q * kLnThreads;
+        if (c < nchunk) {
+            float dx[8];
+            f16x8 cv;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                dx[e] = (float)h(prev[q][e] - cur[q][e]);
+                cv[e] = h(cur[q][e]);
+            }
+            if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + (int64_t)bb * C + c * 8) = cv;
+#pragma unroll
+            for (int m = 0; m < NMIX; m++) {
+                const f16x8 mv = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
+                *reinterpret_cast<f16x8 *>(out + (int64_t)m * out_stride + ro + c * 8) = o;
+            }
+        }
+    }
+}
+
+// One lane per 8 channels; 8 lanes per head.
+__global__ __launch_bounds__(256) void tmix_mid_kernel(
+    const int64_t nchunks, const int C, f16 *__restrict__ k, f16 *__restrict__ v, const f16 *__restrict__ a_pre,
+    const f16 *__restrict__ vg_pre, const f16 *__restrict__ v_first, const f16 *__restrict__ k_k,
+    const f16 *__restrict__ k_a, f16 *__restrict__ neg_kk, f16 *__restrict__ kka) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = g < nchunks;
+    const int64_t off = (live ? g : 0) * 8;
+    const int ch = (int)(off % C);
+    const f16x8 kv = *reinterpret_cast<const f16x8 *>(k + off);
+    const f16x8 ap = *reinterpret_cast<const f16x8 *>(a_pre + off);
+    const f16x8 kkv = *reinterpret_cast<const f16x8 *>(k_k + ch);
+    const f16x8 kav = *reinterpret_cast<const f16x8 *>(k_a + ch);
+    float kk_in[8], ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        kk_in[e] = (float)h((float)kv[e] * (float)kkv[e]);
+        ss += kk_in[e] * kk_in[e];
+    }
+    ss = head_sum(ss);
+    float nrm = (float)h(sqrtf(ss));           // torch.norm -> binary16, clamp_min(1e-12 -> 0 in binary16)
+    nrm = nrm > 0.f ? nrm : 0.f;
+    f16x8 ko, nk, ka;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float a = (float)h(sigmoid_f((float)ap[e]));
+        const float kk = (float)h(kk_in[e] / nrm);
+        const float t1 = (float)h(a - 1.0f);
+        const float t2 = (float)h(t1 * (float)kav[e]);
+        const float t3 = (float)h(1.0f + t2);
+        ko[e] = h((float)kv[e] * t3);
+        nk[e] = h(-kk);
+        ka[e] = h(kk * a);
+    }
+    if (live) {
+        *reinterpret_cast<f16x8 *>(k + off) = ko;
+        *reinterpret_cast<f16x8 *>(neg_kk + off) = nk;
+        *reinterpret_cast<f16x8 *>(kka + off) = ka;
+        if (v_first) {
+            const f16x8 vv = *reinterpret_cast<const f16x8 *>(v + off);
+            const f16x8 vf = *reinterpret_cast<const f16x8 *>(v_first + off);
+            const f16x8 gp = *reinterpret_cast<const f16x8 *>(vg_pre + off);
+            f16x8 vo;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float gate = (float)h(sigmoid_f((float)gp[e]));
+                const float d = (float)h((float)vf[e] - (float)vv[e]);
+                vo[e] = h((float)vv[e] + (float)h(d * gate));
+            }
+            *reinterpret_cast<f16x8 *>(v + off) = vo;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tmix_post_kernel(
+    const int64_t nchunks, const int C, const f16 *__restrict__ y, const f16 *__restrict__ r, const f16 *__restrict__ k,
+    const f16 *__restrict__ v, const f16 *__restrict__ g, const f16 *__restrict__ r_k, const f16 *__restrict__ lnx_w,
+    const f16 *__restrict__ lnx_b, const float eps, f16 *__restrict__ out) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = gi < nchunks;
+    const int64_t off = (live ? gi : 0) * 8;
+    const int ch = (int)(off % C);
+    const f16x8 yv = *reinterpret_cast<const f16x8 *>(y + off);
+    const f16x8 rv = *reinterpret_cast<const f16x8 *>(r + off);
+    const f16x8 kv = *reinterpret_cast<const f16x8 *>(k + off);
+    const f16x8 rkv = *reinterpret_cast<const f16x8 *>(r_k + ch);
+    float s = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        s += (float)yv[e];
+        bsum += (float)h((float)h((float)rv[e] * (float)kv[e]) * (float)rkv[e]);
+    }
+    const float mean = head_sum(s) * (1.0f / 64.0f);
+    const float bonus = (float)h(head_sum(bsum));
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float d = (float)yv[e] - mean;
+        s2 += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(head_sum(s2) * (1.0f / 64.0f) + eps);
+    if (live) {
+        const f16x8 vv = *reinterpret_cast<const f16x8 *>(v + off);
+        const f16x8 gv = *reinterpret_cast<const f16x8 *>(g + off);
+        const f16x8 wv = *reinterpret_cast<const f16x8 *>(lnx_w + ch);
+        const f16x8 bv = *reinterpret_cast<const f16x8 *>(lnx_b + ch);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float gn = (float)h(((float)yv[e] - mean) * rstd * (float)wv[e] + (float)bv[e]);
+            const float t = (float)h(gn + (float)h(bonus * (float)vv[e]));
+            o[e] = h(t * (float)gv[e]);
+        }
+        *reinterpret_cast<f16x8 *>(out + off) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_sq_kernel(const int64_t nchunks, f16 *__restrict__ x) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gi >= nchunks) return;
+    f16x8 v = *reinterpret_cast<const f16x8 *>(x + gi * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float t = (float)v[e] > 0.f ? (float)v[e] : 0.f;
+        v[e] = h(t * t);
+    }
+    *reinterpret_cast<f16x8 *>(x + gi * 8) = v;
+}
+
+inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+}  // namespace
+
+extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
+                                const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
+                                const void *mix, void *out, int64_t out_stride, void *stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
+    if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;
+    if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
+    if (n_mix > 0 && (!prev_in || !prev_out || !mix)) return CHIRRUP_E_NULL;
+    if (n_mix > 0 && T > 1 && prev_in == prev_out) return CHIRRUP_E_UNSUPPORTED;  // rows race on the carry
+    if (mis16(x) || mis16(delta) || mis16(x_out) || mis16(ln_w) || mis16(ln_b) || mis16(prev_in) || mis16(prev_out) ||
+        mis16(mix) || mis16(out) || (out_stride & 7))
+        return CHIRRUP_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)(B * T)), block(kLnThreads);
+#define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
+             (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride
+    if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
+    else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
+    else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);
+#undef ARGS
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_tmix_mid(int64_t rows, int C, void *k, void *v, const void *a_pre, const void *vg_pre,
+                              const void *v_first, const void *k_k, const void *k_a, void *neg_kk, void *kka,
+                              void *stream) {
+    if (rows <= 0 || C <= 0 || (C & 63)) return CHIRRUP_E_SHAPE;
+    if (!k || !v || !a_pre || !k_k || !k_a || !neg_kk || !kka) return CHIRRUP_E_NULL;
+    if ((v_first == nullptr) != (vg_pre == nullptr)) return CHIRRUP_E_NULL;
+    if (mis16(k) || mis16(v) || mis16(a_pre) || mis16(vg_pre) || mis16(v_first) || mis16(k_k) || mis16(k_a) ||
+        mis16(neg_kk) || mis16(kka))
+        return CHIRRUP_E_ALIGN;
+    const int64_t nchunks = rows * (C / 8);
+    hipLaunchKernelGGL(tmix_mid_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nchunks, C, (f16 *)k, (f16 *)v, (const f16 *)a_pre,
+                       (const f16 *)vg_pre, (const f16 *)v_first, (const f16 *)k_k, (const f16 *)k_a, (f16 *)neg_kk,
+                       (f16 *)kka);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_tmix_post(int64_t rows, int C, const void *y, const void *r, const void *k, const void *v,
+                               const void *g, const void *r_k, const void *lnx_w, const void *lnx_b, float eps,
+                               void *out, void *stream) {
+    if (rows <= 0 || C <= 0 || (C & 63)) return CHIRRUP_E_SHAPE;
+    if (!y || !r || !k || !v || !g || !r_k || !lnx_w || !lnx_b || !out) return CHIRRUP_E_NULL;
+    if (mis16(y) || mis16(r) || mis16(k) || mis16(v) || mis16(g) || mis16(r_k) || mis16(lnx_w) || mis16(lnx_b) || mis16(out))
+        return CHIRRUP_E_ALIGN;
+    const int64_t nchunks = rows * (C / 8);
+    hipLaunchKernelGGL(tmix_post_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nchunks, C, (const f16 *)y, (const f16 *)r, (const f16 *)k,
+                       (const f16 *)v, (const f16 *)g, (const f16 *)r_k, (const f16 *)lnx_w, (const f16 *)lnx_b, eps,
+                       (f16 *)out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_relu_sq(int64_t n, void *x, void *stream) {
+    if (n <= 0 || (n & 7)) return CHIRRUP_E_SHAPE;
+    if (!x) return CHIRRUP_E_NULL;
+    if (mis16(x)) return CHIRRUP_E_ALIGN;
+    const int64_t nchunks = n / 8;
+    hipLaunchKernelGGL(relu_sq_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), nchunks, (f16 *)x);
+    return (int)hipGetLastError();
+}

@@ -145,6 +145,61 @@ def mm8_one(N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
     _lib.check(rc, "mm8_one")
 
 
+# ---------------------------------------------------------------------------------------------
+# fused element-wise chains (csrc/elementwise.hip)
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk16(name, t, numel=None):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+        raise _lib.ChirrupAmdError(f"{name}: expected a contiguous GPU fp16 tensor")
+    if numel is not None and t.numel() != numel:
+        raise _lib.ChirrupAmdError(f"{name}: expected {numel} elements, got {t.numel()}")
+
+
+def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out) -> None:
+    """x_new = x (+delta) -> x_out; cur = LN(x_new); out[m] = cur + (shifted - cur) * mix[m]
+    (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h."""
+    n_mix = 0 if mix is None else mix.shape[0]
+    for name, t in (("x", x), ("delta", delta), ("x_out", x_out)):
+        _chk16(name, t, B * T * C)
+    _chk16("ln_w", ln_w, C), _chk16("ln_b", ln_b, C)
+    _chk16("out", out, max(n_mix, 1) * B * T * C)
+    if n_mix:
+        _chk16("mix", mix, n_mix * C), _chk16("prev_in", prev_in, B * C), _chk16("prev_out", prev_out, B * C)
+    rc = _lib.load().rwkv7_add_ln_mix(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
+                                      _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _stream())
+    _lib.check(rc, "rwkv7_add_ln_mix")
+
+
+def tmix_mid(rows: int, C: int, k, v, a_pre, vg_pre, v_first, k_k, k_a, neg_kk, kka) -> None:
+    for name, t in (("k", k), ("v", v), ("a_pre", a_pre), ("vg_pre", vg_pre), ("v_first", v_first), ("neg_kk", neg_kk),
+                    ("kka", kka)):
+        _chk16(name, t, rows * C)
+    _chk16("k_k", k_k, C), _chk16("k_a", k_a, C)
+    rc = _lib.load().rwkv7_tmix_mid(rows, C, _ptr(k), _ptr(v), _ptr(a_pre), _ptr(vg_pre), _ptr(v_first), _ptr(k_k),
+                                    _ptr(k_a), _ptr(neg_kk), _ptr(kka), _stream())
+    _lib.check(rc, "rwkv7_tmix_mid")
+
+
+def tmix_post(rows: int, C: int, y, r, k, v, g, r_k, lnx_w, lnx_b, eps: float, out) -> None:
+    for name, t in (("y", y), ("r", r), ("k", k), ("v", v), ("g", g), ("out", out)):
+        _chk16(name, t, rows * C)
+    _chk16("r_k", r_k, C), _chk16("lnx_w", lnx_w, C), _chk16("lnx_b", lnx_b, C)
+    rc = _lib.load().rwkv7_tmix_post(rows, C, _ptr(y), _ptr(r), _ptr(k), _ptr(v), _ptr(g), _ptr(r_k), _ptr(lnx_w),
+                                     _ptr(lnx_b), eps, _ptr(out), _stream())
+    _lib.check(rc, "rwkv7_tmix_post")
+
+
+def relu_sq_(x) -> None:
+    _chk16("x", x)
+    rc = _lib.load().rwkv7_relu_sq(x.numel(), _ptr(x), _stream())
+    _lib.check(rc, "rwkv7_relu_sq")
+
+
 _registered = False
 
 

@@ -43,6 +43,13 @@ def convert_checkpoint(z_disk: Dict[str, torch.Tensor], device) -> Dict[str, tor
     r_k; :206 emb <- LN0(emb))."""
     z: Dict[str, torch.Tensor] = {}
     for name, t in z_disk.items():
+        if name.endswith("ffn.value.weight"):
+            # The reference stores this one transposed ([4C, C]) for its sparse bsz=1 kernel and then
+            # runs `k @ V_` as an NN GEMM.  Keep the [C, 4C] bytes contiguous (k @ V_ becomes the NT
+            # GEMM form, 2.3x faster through hipBLASLt at M = 200) and expose the reference's
+            # [4C, C] shape as a view.
+            z[name] = t.squeeze().to(dtype=DTYPE, device=device).contiguous().t()
+            continue
         if any(s in name for s in _T_KEYS):
             t = t.t()
         t = t.squeeze().to(dtype=DTYPE, device=device)
@@ -79,7 +86,8 @@ class _Layer:
         self.R, self.K, self.V, self.O = (z[a + n + ".weight"] for n in ("receptance", "key", "value", "output"))
         self.lnx_w, self.lnx_b = z[a + "ln_x.weight"], z[a + "ln_x.bias"]
         self.f_x_k, self.f_K, self.f_V = z[f + "x_k"], z[f + "key.weight"], z[f + "value.weight"]
-        self.mix6 = None
+        # the six lerp vectors as one [6, C] block for the fused LN + token-shift kernel
+        self.mix6 = torch.stack([self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g]).contiguous()
 
 
 class RWKV_x070:
@@ -224,6 +232,8 @@ class RWKV_x070:
         return DecodeGraph(self, state, warmup)
 
     def _forward_embedded(self, x, state, T, full_output):
+        if self.fused:
+            return self._forward_embedded_fused(x, state, T, full_output)
         z = self.z
         s0, s1, s2 = state
         v_first = None
@@ -237,6 +247,64 @@ class RWKV_x070:
             x = x[:, -1, :]
         x = F.layer_norm(x, (self.n_embd,), weight=z["ln_out.weight"], bias=z["ln_out.bias"])
         return F.linear(x, z["head.weight"])
+
+    def _forward_embedded_fused(self, x, state, T, full_output):
+        """Same arithmetic as _forward_embedded with every element-wise chain in one HIP kernel
+        (csrc/elementwise.hip).  x [B,T,C] is consumed (updated in place as the residual stream)."""
+        z = self.z
+        s0, s1, s2 = state
+        B, _, C = x.shape
+        H, rows, dev = self.n_head, B * T, x.device
+        x = x.contiguous()
+        new = lambda *shape: torch.empty(shape, dtype=DTYPE, device=dev)
+        mixed, kin, y, o_in, neg_kk, kka = new(6, B, T, C), new(1, B, T, C), new(B, T, C), new(B, T, C), new(B, T, C), new(B, T, C)
+        carry = new(B, C) if T > 1 else None
+        delta, v_first = None, None
+        for i, lw in enumerate(self._layers):
+            for j in (0, 1):
+                if not s0[i][j].is_contiguous():
+                    raise ops._lib.ChirrupAmdError("state[0][layer][j] view must be contiguous (slice the batch dim only)")
+            # residual add of the previous channel-mix + LN1 + token shift + six lerps
+            prev = s0[i][0]
+            ops.add_ln_mix(B, T, C, x, delta, x if delta is not None else None, lw.ln1_w, lw.ln1_b, 1e-5, prev,
+                           prev if T == 1 else carry, lw.mix6, mixed)
+            if T > 1:
+                prev.copy_(carry)
+            xr, xw, xk, xv, xa, xg = mixed.unbind(0)
+            r = F.linear(xr, lw.R)
+            k = F.linear(xk, lw.K)
+            v = F.linear(xv, lw.V)
+            w = F.linear(torch.tanh(F.linear(xw, lw.w1)), lw.w2, bias=lw.w0)
+            a_pre = F.linear(F.linear(xa, lw.a1), lw.a2, bias=lw.a0)
+            g = F.linear(torch.sigmoid(F.linear(xg, lw.g1)), lw.g2)
+            vg_pre = F.linear(F.linear(xv, lw.v1), lw.v2, bias=lw.v0) if i > 0 else None
+            ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)
+            if i == 0:
+                v_first = v
+            if not s1[i].is_contiguous():
+                raise ops._lib.ChirrupAmdError("state[1][layer] view must be contiguous (slice the batch dim only)")
+            self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, s2)
+            ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
+            att = F.linear(o_in, lw.O)
+            # residual add of the time-mix + LN2 + token shift + one lerp
+            prev = s0[i][1]
+            ops.add_ln_mix(B, T, C, x, att, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
+                           lw.f_x_k.view(1, C), kin)
+            if T > 1:
+                prev.copy_(carry)
+            kf = F.linear(kin[0], lw.f_K)
+            ops.relu_sq_(kf)
+            delta = kf @ lw.f_V
+        if T > 1 and not full_output:
+            x, delta, rows_out = x[:, -1, :].contiguous(), delta[:, -1, :].contiguous(), (B, 1)
+        else:
+            rows_out = (B, T)
+        xo = new(rows_out[0], rows_out[1], C)
+        ops.add_ln_mix(rows_out[0], rows_out[1], C, x, delta, None, z["ln_out.weight"], z["ln_out.bias"], 1e-5, None, None,
+                       None, xo)
+        if not full_output:
+            xo = xo.view(B, C)
+        return F.linear(xo, z["head.weight"])
 
     def _tmix(self, layer_id, lw: _Layer, x, x_prev, v_first, S, elapsed_t):
         """Time-mix block, arithmetic of RWKV_x070_TMix_seq_batch (rwkv7.py:618-649).

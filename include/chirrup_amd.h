@@ -92,6 +92,39 @@ int mm8_seq(int B, int N, int M, const void *x, int x_stride, const void *w, int
 int mm8_one(int N, int M, const void *x, const void *w, int w_stride, const void *mx,
             const void *rx, const void *my, const void *ry, float *y, void *stream);
 
+/*
+ * Fused element-wise chains between the GEMMs of one layer.  They replace runs of separate torch
+ * ops in Albatross/rwkv7.py (lines given); every op of a chain still rounds to binary16 once, as
+ * in the reference's eager execution, reductions accumulate in binary32.  All tensors binary16,
+ * rows of C channels, C % 64 == 0, 16-byte aligned.
+ *
+ * rwkv7_add_ln_mix: x_new = x (+ delta, may be NULL) -> x_out (may be NULL or alias x);
+ *   cur = LayerNorm(x_new; ln_w, ln_b, eps); with n_mix in {1, 6}: token shift against the previous
+ *   row (t > 0) or prev_in[b] (t == 0), out[m] = cur + (prev - cur) * mix[m], prev_out[b] = cur of
+ *   the last row; with n_mix == 0: out = cur.   x,delta,x_out,out[m]: [B][T][C]; prev_*: [B][C];
+ *   mix: [n_mix][C]; out planes are out_stride elements apart.  T > 1 needs prev_out != prev_in.
+ *   Replaces rwkv7.py:523 + :621-623 (n_mix 6), :531-533 + :675-677 (n_mix 1), :548-550 (n_mix 0).
+ */
+int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
+                     const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
+                     const void *mix, void *out, int64_t out_stride, void *stream);
+
+/* rwkv7.py:629-637: a = sigmoid(a_pre); kk = normalize(k*k_k) per 64-channel head;
+ * k <- k*(1+(a-1)*k_a) in place; neg_kk = -kk; kka = kk*a; and, when v_first != NULL (layer > 0),
+ * v <- v + (v_first - v)*sigmoid(vg_pre) in place.  rows = B*T. */
+int rwkv7_tmix_mid(int64_t rows, int C, void *k, void *v, const void *a_pre, const void *vg_pre,
+                   const void *v_first, const void *k_k, const void *k_a, void *neg_kk, void *kka,
+                   void *stream);
+
+/* rwkv7.py:647-649 up to the output projection: out = (group_norm_H(y; lnx_w, lnx_b, eps) +
+ * (sum_head r*k*r_k) * v) * g. */
+int rwkv7_tmix_post(int64_t rows, int C, const void *y, const void *r, const void *k, const void *v,
+                    const void *g, const void *r_k, const void *lnx_w, const void *lnx_b, float eps,
+                    void *out, void *stream);
+
+/* rwkv7.py:678: x <- relu(x)**2 in place over n elements (n % 8 == 0). */
+int rwkv7_relu_sq(int64_t n, void *x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

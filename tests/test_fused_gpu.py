@@ -1,0 +1,126 @@
+"""Unit parity of the fused element-wise HIP kernels (csrc/elementwise.hip) against the numpy
+oracle's per-op restatement (oracle/rwkv7_np.py).  Element-wise parts must be bit-identical; the
+binary32 reductions (norms, head sums) may differ in summation order, which can move a result by
+one binary16 ulp on a small fraction of elements."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rwkv7_np as M
+from util import bits
+
+pytestmark = pytest.mark.gpu
+F16, F32 = np.float16, np.float32
+
+
+def ulp_diff(a, b):
+    def key(x):
+        u = bits(x).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u)
+    return np.abs(key(a) - key(b))
+
+
+def assert_close_ulps(got, want, max_ulp=1, max_frac=0.01, name=""):
+    d = ulp_diff(got, want)
+    assert d.max() <= max_ulp, f"{name}: max ulp diff {d.max()}"
+    assert (d > 0).mean() <= max_frac, f"{name}: {(d > 0).mean():.4f} of elements differ"
+
+
+def cu(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+@pytest.mark.parametrize("B,T,C,n_mix,with_delta", [(3, 1, 128, 6, True), (2, 4, 768, 6, True), (5, 1, 4096, 1, True),
+                                                    (2, 3, 256, 1, False), (4, 1, 2048, 0, True), (200, 1, 4096, 6, True)])
+def test_add_ln_mix(B, T, C, n_mix, with_delta):
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(B * 7 + T + C)
+    x = rng.standard_normal((B, T, C)).astype(F16)
+    delta = (rng.standard_normal((B, T, C)) * 0.5).astype(F16) if with_delta else None
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(F16)
+    b = (0.1 * rng.standard_normal(C)).astype(F16)
+    prev = rng.standard_normal((B, C)).astype(F16)
+    mix = rng.uniform(0, 1, (max(n_mix, 1), C)).astype(F16)
+    # oracle
+    xn = x + delta if with_delta else x
+    cur = M.layer_norm(xn, w, b)
+    if n_mix:
+        dx = np.concatenate([prev[:, None], cur[:, :-1]], 1) - cur
+        want = np.stack([cur + dx * mix[m] for m in range(n_mix)])
+    else:
+        want = cur[None]
+    tx, tprev = cu(x), cu(prev)
+    out = torch.empty((max(n_mix, 1), B, T, C), dtype=torch.float16, device="cuda")
+    prev_out = tprev if T == 1 else torch.empty_like(tprev)
+    ops.add_ln_mix(B, T, C, tx, cu(delta) if with_delta else None, tx if with_delta else None, cu(w), cu(b), 1e-5,
+                   tprev if n_mix else None, prev_out if n_mix else None, cu(mix[:n_mix]) if n_mix else None, out)
+    got = out.cpu().numpy()
+    if with_delta:
+        assert np.array_equal(bits(tx.cpu().numpy()), bits(xn))          # residual add is exact
+    assert_close_ulps(got, want, 2, 0.02, "mixed")
+    if n_mix:
+        assert_close_ulps(prev_out.cpu().numpy(), cur[:, -1], 1, 0.01, "carry")
+
+
+@pytest.mark.parametrize("rows,C,layer0", [(3, 128, True), (7, 768, False), (200, 4096, False)])
+def test_tmix_mid(rows, C, layer0):
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(rows + C)
+    H = C // 64
+    k = rng.standard_normal((rows, C)).astype(F16)
+    v = rng.standard_normal((rows, C)).astype(F16)
+    a_pre = rng.standard_normal((rows, C)).astype(F16)
+    vg_pre = rng.standard_normal((rows, C)).astype(F16)
+    v_first = rng.standard_normal((rows, C)).astype(F16)
+    k_k = (0.85 + 0.05 * rng.standard_normal(C)).astype(F16)
+    k_a = (1 + 0.05 * rng.standard_normal(C)).astype(F16)
+    # oracle: oracle/rwkv7_np.tmix lines for rwkv7.py:629-637
+    a = M.sigmoid_h(a_pre)
+    kk_in = (k * k_k).reshape(rows, H, 64)
+    nrm = np.sqrt((kk_in.astype(F32) ** 2).sum(-1, keepdims=True, dtype=F32)).astype(F16)
+    kk = (kk_in / np.maximum(nrm, F16(1e-12))).reshape(rows, C)
+    k_want = k * (F16(1.0) + (a - F16(1.0)) * k_a)
+    kka_want = kk * a
+    v_want = v if layer0 else v + (v_first - v) * M.sigmoid_h(vg_pre)
+    tk, tv = cu(k), cu(v)
+    nk, kka = torch.empty_like(tk), torch.empty_like(tk)
+    ops.tmix_mid(rows, C, tk, tv, cu(a_pre), None if layer0 else cu(vg_pre), None if layer0 else cu(v_first), cu(k_k),
+                 cu(k_a), nk, kka)
+    assert_close_ulps(tk.cpu().numpy(), k_want, 1, 0.005, "k")          # sigmoid: device expf vs numpy
+    assert_close_ulps(nk.cpu().numpy(), -kk, 1, 0.01, "neg_kk")
+    assert_close_ulps(kka.cpu().numpy(), kka_want, 2, 0.02, "kka")
+    assert_close_ulps(tv.cpu().numpy(), v_want, 1, 0.005, "v")
+
+
+@pytest.mark.parametrize("rows,C", [(3, 128), (7, 768), (200, 4096)])
+def test_tmix_post(rows, C):
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(rows * 3 + C)
+    H = C // 64
+    y = (rng.standard_normal((rows, C)) * 2).astype(F16)
+    r, k, v, g = (rng.standard_normal((rows, C)).astype(F16) for _ in range(4))
+    r_k = (0.1 * rng.standard_normal(C)).astype(F16)
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(F16)
+    b = (0.1 * rng.standard_normal(C)).astype(F16)
+    gn = M.group_norm_heads(y, H, w, b)
+    bonus = ((r * k * r_k).reshape(rows, H, 64).astype(F32).sum(-1, keepdims=True, dtype=F32)).astype(F16)
+    want = (gn + (bonus * v.reshape(rows, H, 64)).reshape(rows, C)) * g
+    out = torch.empty((rows, C), dtype=torch.float16, device="cuda")
+    ops.tmix_post(rows, C, cu(y), cu(r), cu(k), cu(v), cu(g), cu(r_k), cu(w), cu(b), 64e-5, out)
+    assert_close_ulps(out.cpu().numpy(), want, 2, 0.03, "out")
+
+
+def test_relu_sq_exact():
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((200, 16384)) * 3).astype(F16)
+    x[0, :4] = [F16(-0.0), F16(0.0), F16(250.0), F16(300.0)]          # 300^2 overflows to inf like torch
+    t = cu(x)
+    ops.relu_sq_(t)
+    with np.errstate(over="ignore"):
+        want = np.maximum(x, F16(0)) * np.maximum(x, F16(0))
+    assert np.array_equal(bits(t.cpu().numpy()), bits(want))
