@@ -281,6 +281,20 @@ __global__ __launch_bounds__(256) void relu_sq_kernel(const int64_t nchunks, f16
     *reinterpret_cast<f16x8 *>(x + gi * 8) = v;
 }
 
+// LoRA hidden activations, planes [v, w, a, g] of D columns each: w -> tanh, g -> sigmoid
+// (rwkv7.py:626 torch.tanh(xw@w1), :630 torch.sigmoid(xg@g1)); a and v pass through (:629, :637).
+__global__ __launch_bounds__(256) void lora_act_kernel(const int64_t plane_chunks, const int first_plane,
+                                                       f16 *__restrict__ hbuf, const int nplanes) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int plane = blockIdx.y + first_plane;          // 0=v 1=w 2=a 3=g
+    if (gi >= plane_chunks || (plane != 1 && plane != 3)) return;
+    f16 *p = hbuf + ((int64_t)blockIdx.y * plane_chunks + gi) * 8;
+    f16x8 v = *reinterpret_cast<const f16x8 *>(p);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = plane == 1 ? h(tanhf((float)v[e])) : h(sigmoid_f((float)v[e]));
+    *reinterpret_cast<f16x8 *>(p) = v;
+}
+
 inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 
 }  // namespace
@@ -346,5 +360,16 @@ extern "C" int rwkv7_relu_sq(int64_t n, void *x, void *stream) {
     const int64_t nchunks = n / 8;
     hipLaunchKernelGGL(relu_sq_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), nchunks, (f16 *)x);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems, void *hbuf, void *stream) {
+    if (nplanes <= 0 || first_plane < 0 || first_plane + nplanes > 4 || plane_elems <= 0 || (plane_elems & 7))
+        return CHIRRUP_E_SHAPE;
+    if (!hbuf) return CHIRRUP_E_NULL;
+    if (mis16(hbuf)) return CHIRRUP_E_ALIGN;
+    const int64_t chunks = plane_elems / 8;
+    hipLaunchKernelGGL(lora_act_kernel, dim3((unsigned)((chunks + 255) / 256), (unsigned)nplanes), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), chunks, first_plane, (f16 *)hbuf, nplanes);
     return (int)hipGetLastError();
 }

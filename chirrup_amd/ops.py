@@ -200,6 +200,14 @@ def relu_sq_(x) -> None:
     _lib.check(rc, "rwkv7_relu_sq")
 
 
+def lora_act_(hbuf, first_plane: int) -> None:
+    """hbuf [n, rows, D] fp16, planes first_plane.. of [v, w, a, g]: tanh on w, sigmoid on g."""
+    _chk16("hbuf", hbuf)
+    n = hbuf.shape[0]
+    rc = _lib.load().rwkv7_lora_act(n, first_plane, hbuf.numel() // n, _ptr(hbuf), _stream())
+    _lib.check(rc, "rwkv7_lora_act")
+
+
 _registered = False
 
 

@@ -58,6 +58,8 @@ def convert_checkpoint(z_disk: Dict[str, torch.Tensor], device) -> Dict[str, tor
         z[name] = t.contiguous()
     C = z["emb.weight"].shape[1]
     emb = z["emb.weight"]
+    if emb.data_ptr() == z_disk["emb.weight"].data_ptr():      # never write into the caller's checkpoint
+        emb = z["emb.weight"] = emb.clone()
     # chunked so a 65536 x 4096 table never needs a second full-size fp32 copy
     for lo in range(0, emb.shape[0], 8192):
         sl = slice(lo, lo + 8192)
@@ -74,7 +76,7 @@ class _Layer:
 
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
-                 "f_K", "f_V", "mix6")
+                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -86,8 +88,39 @@ class _Layer:
         self.R, self.K, self.V, self.O = (z[a + n + ".weight"] for n in ("receptance", "key", "value", "output"))
         self.lnx_w, self.lnx_b = z[a + "ln_x.weight"], z[a + "ln_x.bias"]
         self.f_x_k, self.f_K, self.f_V = z[f + "x_k"], z[f + "key.weight"], z[f + "value.weight"]
-        # the six lerp vectors as one [6, C] block for the fused LN + token-shift kernel
-        self.mix6 = torch.stack([self.x_r, self.x_w, self.x_k, self.x_v, self.x_a, self.x_g]).contiguous()
+
+    def pack_for_fused(self, z, i):
+        """Regroup this layer's weights for the fused path (no extra copies are kept: the reference's
+        keys in ``z`` become views into the packed tensors).
+          mix6  [6,C]        lerp vectors in plane order (r, k, v, w, a, g): planes 0:3 feed ONE batched
+                             GEMM against rkv, planes 2:6 (v, w, a, g) ONE batched GEMM against lora1
+          rkv   [3,C,C]      receptance / key / value weights
+          lora1 [4,Dmax,C]   v1, w1, a1, g1 zero-padded to the widest rank;  lora2 [4,C,Dmax] likewise
+          lbias [4,1,C]      v0, w0, a0, 0  (added inside the second batched GEMM: one rounding)"""
+        a = f"blocks.{i}.att."
+        dev, C = self.R.device, self.R.shape[0]
+        self.mix6 = torch.stack([self.x_r, self.x_k, self.x_v, self.x_w, self.x_a, self.x_g]).contiguous()
+        self.rkv = torch.stack([self.R, self.K, self.V]).contiguous()
+        for j, n in enumerate(("receptance", "key", "value")):
+            z[a + n + ".weight"] = self.rkv[j]
+        self.R, self.K, self.V = self.rkv[0], self.rkv[1], self.rkv[2]
+        downs, ups = (self.v1, self.w1, self.a1, self.g1), (self.v2, self.w2, self.a2, self.g2)
+        dmax = max(t.shape[0] for t in downs)
+        dmax = (dmax + 31) // 32 * 32
+        self.lora1 = torch.zeros((4, dmax, C), dtype=DTYPE, device=dev)
+        self.lora2 = torch.zeros((4, C, dmax), dtype=DTYPE, device=dev)
+        for j, (d_, u_, n) in enumerate(zip(downs, ups, "vwag")):
+            D = d_.shape[0]
+            self.lora1[j, :D].copy_(d_)
+            self.lora2[j, :, :D].copy_(u_)
+            if not (i == 0 and n == "v"):             # layer 0 aliases v* to a* (rwkv7.py:207-209)
+                z[a + n + "1"], z[a + n + "2"] = self.lora1[j, :D], self.lora2[j, :, :D]
+                setattr(self, n + "1", z[a + n + "1"]), setattr(self, n + "2", z[a + n + "2"])
+        if i == 0:
+            for sfx in ("1", "2"):
+                z[a + "v" + sfx] = z[a + "a" + sfx]
+                setattr(self, "v" + sfx, z[a + "a" + sfx])
+        self.lbias = torch.stack([self.v0, self.w0, self.a0, torch.zeros_like(self.a0)]).view(4, 1, C).contiguous()
 
 
 class RWKV_x070:
@@ -112,6 +145,10 @@ class RWKV_x070:
         self.fused = fused and self.device.type == "cuda"
         self._wkv = wkv_impl if wkv_impl is not None else ops.forward_seq
         self._layers = [_Layer(self.z, i) for i in range(self.n_layer)] if auto_load else []
+        if self.fused:
+            for i, lw in enumerate(self._layers):
+                lw.pack_for_fused(self.z, i)
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ reference surface
     def generate_zero_state(self, bsz: int):
@@ -270,14 +307,15 @@ class RWKV_x070:
                            prev if T == 1 else carry, lw.mix6, mixed)
             if T > 1:
                 prev.copy_(carry)
-            xr, xw, xk, xv, xa, xg = mixed.unbind(0)
-            r = F.linear(xr, lw.R)
-            k = F.linear(xk, lw.K)
-            v = F.linear(xv, lw.V)
-            w = F.linear(torch.tanh(F.linear(xw, lw.w1)), lw.w2, bias=lw.w0)
-            a_pre = F.linear(F.linear(xa, lw.a1), lw.a2, bias=lw.a0)
-            g = F.linear(torch.sigmoid(F.linear(xg, lw.g1)), lw.g2)
-            vg_pre = F.linear(F.linear(xv, lw.v1), lw.v2, bias=lw.v0) if i > 0 else None
+            # planes: 0 r, 1 k, 2 v, 3 w, 4 a, 5 g
+            rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))            # one launch for R, K, V
+            r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
+            p0 = 1 if i == 0 else 0                                                           # layer 0 has no v gate
+            hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
+            ops.lora_act_(hid, p0)                                                            # tanh(w), sigmoid(g)
+            up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))             # + v0 / w0 / a0 / 0
+            vg_pre = up[0].view(B, T, C) if i > 0 else None
+            w, a_pre, g = (up[j - p0].view(B, T, C) for j in (1, 2, 3))
             ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)
             if i == 0:
                 v_first = v

@@ -122,6 +122,11 @@ int rwkv7_tmix_post(int64_t rows, int C, const void *y, const void *r, const voi
                     const void *g, const void *r_k, const void *lnx_w, const void *lnx_b, float eps,
                     void *out, void *stream);
 
+/* LoRA hidden activations in place on `nplanes` consecutive planes of plane_elems binary16 values,
+ * plane ids first_plane.. in the order [v, w, a, g]: w -> tanh (rwkv7.py:626), g -> sigmoid (:630),
+ * a and v unchanged (:629, :637). */
+int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems, void *hbuf, void *stream);
+
 /* rwkv7.py:678: x <- relu(x)**2 in place over n elements (n % 8 == 0). */
 int rwkv7_relu_sq(int64_t n, void *x, void *stream);
 

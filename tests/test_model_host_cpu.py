@@ -116,3 +116,19 @@ def test_no_silent_fallback():
     st = m.generate_zero_state(1)
     with pytest.raises(ChirrupAmdError):
         m.forward_seq_batch_seperate([[1]], st)
+
+
+def test_constructor_does_not_modify_the_callers_checkpoint(oracle):
+    """convert_checkpoint bakes LN0 into the embedding (rwkv7.py:206); on a same-device fp16
+    checkpoint that must happen on a copy."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k].copy()) for k in d.files if k.startswith("w:")}
+    before = {k: v.clone() for k, v in zd.items()}
+    args = types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
+    m1 = RWKV_x070(args, state_dict=zd, device="cpu", fused=False)
+    m2 = RWKV_x070(types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused"), state_dict=zd, device="cpu", fused=False)
+    for k, v in zd.items():
+        assert torch.equal(v, before[k]), k
+    assert torch.equal(m1.z["emb.weight"], m2.z["emb.weight"])
