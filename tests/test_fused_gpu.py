@@ -63,7 +63,8 @@ def test_add_ln_mix(B, T, C, n_mix, with_delta):
     got = out.cpu().numpy()
     if with_delta:
         assert np.array_equal(bits(tx.cpu().numpy()), bits(xn))          # residual add is exact
-    assert_close_ulps(got, want, 2, 0.02, "mixed")
+    # LN outputs reach |x| ~ 4-5 (ulp 3.9e-3); a one-ulp flip there can survive a cancelling lerp
+    assert_close_ulps(got, want, 2, 0.02, "mixed", atol=4e-3)
     if n_mix:
         assert_close_ulps(prev_out.cpu().numpy(), cur[:, -1], 1, 0.01, "carry")
 
