@@ -112,10 +112,12 @@ template <int NMIX>
 __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int T, const int C, const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
-    f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride) {
+    f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
+    const int32_t *__restrict__ slot_idx) {
     __shared__ float red[kLnThreads / 64];
     const int row = blockIdx.x;
     const int bb = row / T, t = row - bb * T;
+    const int64_t slot = slot_idx ? (int64_t)slot_idx[bb] : (int64_t)bb;   // row of the carry tables
     const int nchunk = C >> 3;
     const int64_t ro = (int64_t)row * C;
     float cur[kLnMaxChunks][8];
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         for (int q = 0; q < kLnMaxChunks; q++) {
             const int c = threadIdx.x + q * kLnThreads;
             if (c < nchunk) {
-                const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + (int64_t)bb * C + c * 8);
+                const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + slot * C + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; e++) prev[q][e] = (float)pv[e];
             }
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
                 dx[e] = (float)h(prev[q][e] - cur[q][e]);
                 cv[e] = h(cur[q][e]);
             }
-            if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + (int64_t)bb * C + c * 8) = cv;
+            if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + slot * C + c * 8) = cv;
 #pragma unroll
             for (int m = 0; m < NMIX; m++) {
                 const f16x8 mv = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
@@ -301,7 +303,8 @@ inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                                 const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
-                                const void *mix, void *out, int64_t out_stride, void *stream) {
+                                const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
+                                void *stream) {
     if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
     if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;
     if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
@@ -313,7 +316,7 @@ extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(B * T)), block(kLnThreads);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
-             (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride
+             (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx
     if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
     else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
     else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);

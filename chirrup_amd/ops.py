@@ -160,7 +160,8 @@ def _chk16(name, t, numel=None):
         raise _lib.ChirrupAmdError(f"{name}: expected {numel} elements, got {t.numel()}")
 
 
-def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out) -> None:
+def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out,
+               slot_idx=None) -> None:
     """x_new = x (+delta) -> x_out; cur = LN(x_new); out[m] = cur + (shifted - cur) * mix[m]
     (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h."""
     n_mix = 0 if mix is None else mix.shape[0]
@@ -169,9 +170,17 @@ def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, 
     _chk16("ln_w", ln_w, C), _chk16("ln_b", ln_b, C)
     _chk16("out", out, max(n_mix, 1) * B * T * C)
     if n_mix:
-        _chk16("mix", mix, n_mix * C), _chk16("prev_in", prev_in, B * C), _chk16("prev_out", prev_out, B * C)
+        _chk16("mix", mix, n_mix * C)
+        if slot_idx is None:
+            _chk16("prev_in", prev_in, B * C), _chk16("prev_out", prev_out, B * C)
+        else:
+            _chk16("prev_in", prev_in), _chk16("prev_out", prev_out)
+            _chk(slot_idx, "slot_idx", torch.int32, (B,))
+            if prev_in.numel() % C or prev_out.numel() != prev_in.numel():
+                raise _lib.ChirrupAmdError("prev tables must be [n_slots, C]")
     rc = _lib.load().rwkv7_add_ln_mix(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
-                                      _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _stream())
+                                      _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _ptr(slot_idx),
+                                      _stream())
     _lib.check(rc, "rwkv7_add_ln_mix")
 
 
@@ -198,6 +207,33 @@ def relu_sq_(x) -> None:
     _chk16("x", x)
     rc = _lib.load().rwkv7_relu_sq(x.numel(), _ptr(x), _stream())
     _lib.check(rc, "rwkv7_relu_sq")
+
+
+def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=None, frequency_penalty=None,
+                    slot_idx=None, out=None):
+    """Greedy rows of the worker's decode step in one kernel (see include/chirrup_amd.h):
+    logits fp16 [B,V] is penalised IN PLACE (when occurrence is given), returns int32 ids [B]."""
+    if not logits.is_cuda or logits.dtype != torch.float16 or logits.dim() != 2 or not logits.is_contiguous():
+        raise _lib.ChirrupAmdError("logits: expected contiguous GPU fp16 [B,V]")
+    B, V = logits.shape
+    if out is None:
+        out = torch.empty((B,), dtype=torch.int32, device=logits.device)
+    if occurrence is not None:
+        for name, t in (("occurrence", occurrence), ("alpha_presence", alpha_presence)):
+            if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.shape[-1] != V:
+                raise _lib.ChirrupAmdError(f"{name}: expected contiguous GPU fp32 [n_slots,V]")
+        n_slots = occurrence.shape[0]
+        for name, t in (("penalty_decay", penalty_decay), ("frequency_penalty", frequency_penalty)):
+            if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous() or t.numel() != n_slots:
+                raise _lib.ChirrupAmdError(f"{name}: expected contiguous GPU fp16 with {n_slots} elements")
+        if slot_idx is None and n_slots != B:
+            raise _lib.ChirrupAmdError("penalty tables have a different row count and no slot_idx")
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    rc = _lib.load().rwkv7_penalize_argmax(B, V, _ptr(logits), _ptr(occurrence), _ptr(alpha_presence), _ptr(penalty_decay),
+                                           _ptr(frequency_penalty), _ptr(slot_idx), _ptr(out), _stream())
+    _lib.check(rc, "rwkv7_penalize_argmax")
+    return out
 
 
 def lora_act_(hbuf, first_plane: int) -> None:

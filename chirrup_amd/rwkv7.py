@@ -285,18 +285,45 @@ class RWKV_x070:
         x = F.layer_norm(x, (self.n_embd,), weight=z["ln_out.weight"], bias=z["ln_out.bias"])
         return F.linear(x, z["head.weight"])
 
-    def _forward_embedded_fused(self, x, state, T, full_output):
+    def forward_slots(self, idxs, pool, slot_idx: torch.Tensor, full_output: bool = False):
+        """State-pool form of forward_seq_batch_seperate (not in the reference): ``pool`` is the
+        worker's WHOLE slot table [fp16[L,2,n,C], fp16[L,n,H,64,64], int32[n]] and batch row b lives
+        in slot ``slot_idx[b]`` (int32 [B] on the device, all distinct).  Nothing is gathered or
+        swapped: the kernels address the slot tables directly (SURVEY.md section 8f "next 1")."""
+        if not self.fused:
+            raise ops._lib.ChirrupAmdError("forward_slots needs the fused HIP path (a GPU)")
+        if isinstance(idxs, torch.Tensor):
+            tok = idxs
+        else:
+            assert len({len(t) for t in idxs}) == 1, "here all sequences must have the same length"
+            tok = torch.tensor(idxs, device=self.device, dtype=torch.long)
+        x = self.z["emb.weight"][tok]
+        return self._forward_embedded_fused(x, pool, tok.shape[1], full_output, slot_idx=slot_idx)
+
+    def _forward_embedded_fused(self, x, state, T, full_output, slot_idx=None):
         """Same arithmetic as _forward_embedded with every element-wise chain in one HIP kernel
         (csrc/elementwise.hip).  x [B,T,C] is consumed (updated in place as the residual stream)."""
         z = self.z
         s0, s1, s2 = state
+        if slot_idx is not None:
+            idx64 = slot_idx.long()
+            elapsed = s2.index_select(0, idx64)
+        else:
+            idx64, elapsed = None, s2
         B, _, C = x.shape
         H, rows, dev = self.n_head, B * T, x.device
         x = x.contiguous()
         new = lambda *shape: torch.empty(shape, dtype=DTYPE, device=dev)
         mixed, kin, y, o_in, neg_kk, kka = new(6, B, T, C), new(1, B, T, C), new(B, T, C), new(B, T, C), new(B, T, C), new(B, T, C)
-        carry = new(B, C) if T > 1 else None
+        carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
+
+        def commit_carry(prev):
+            if slot_idx is None:
+                prev.copy_(carry)
+            else:
+                prev.index_copy_(0, idx64, carry.index_select(0, idx64))
+
         for i, lw in enumerate(self._layers):
             for j in (0, 1):
                 if not s0[i][j].is_contiguous():
@@ -304,9 +331,9 @@ class RWKV_x070:
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
             ops.add_ln_mix(B, T, C, x, delta, x if delta is not None else None, lw.ln1_w, lw.ln1_b, 1e-5, prev,
-                           prev if T == 1 else carry, lw.mix6, mixed)
+                           prev if T == 1 else carry, lw.mix6, mixed, slot_idx)
             if T > 1:
-                prev.copy_(carry)
+                commit_carry(prev)
             # planes: 0 r, 1 k, 2 v, 3 w, 4 a, 5 g
             rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))            # one launch for R, K, V
             r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
@@ -321,15 +348,15 @@ class RWKV_x070:
                 v_first = v
             if not s1[i].is_contiguous():
                 raise ops._lib.ChirrupAmdError("state[1][layer] view must be contiguous (slice the batch dim only)")
-            self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, s2)
+            self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
             ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
             att = F.linear(o_in, lw.O)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
             ops.add_ln_mix(B, T, C, x, att, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
-                           lw.f_x_k.view(1, C), kin)
+                           lw.f_x_k.view(1, C), kin, slot_idx)
             if T > 1:
-                prev.copy_(carry)
+                commit_carry(prev)
             kf = F.linear(kin[0], lw.f_K)
             ops.relu_sq_(kf)
             delta = kf @ lw.f_V
@@ -342,6 +369,8 @@ class RWKV_x070:
                        None, xo)
         if not full_output:
             xo = xo.view(B, C)
+        if slot_idx is not None:
+            s2.index_add_(0, idx64, torch.full((B,), T, dtype=s2.dtype, device=s2.device))
         return F.linear(xo, z["head.weight"])
 
     def _tmix(self, layer_id, lw: _Layer, x, x_prev, v_first, S, elapsed_t):

@@ -1,0 +1,393 @@
+"""Continuous-batching worker for one GPU (row A10 of SURVEY.md section 8a; boundary B4).
+
+Keeps the reference worker's protocol and scheduling semantics (chirrup/worker.py):
+  * ``Worker(worker_id, gpu_id, model_config, task_queue, master_event_queue, worker_event_queue,
+    batch_size).start()`` runs the loop in the calling thread until a {"type": "shutdown"} event;
+  * slots are classified with ``StateCategory`` (same members / order, :86-92); decode rows and
+    single-token prefill rows share one forward per iteration (:671-742), chunked prefill of at most
+    ``max_forward_seq_len_per_forward`` tokens runs every ``decode_prefill_ratio`` iterations for at
+    most ``max(batch_size/8, 1)`` sequences (:143, :744-776, :854-856);
+  * messages: ("token_generated", (id, text[, logits])), ("task_completed", task),
+    ("cache_prefill", {"state", "prefilled_tokens"}) on the task's output queue (:422-434, :498-501,
+    :556-558), (worker_id, "worker_loaded" | "worker_performance", {...}) on the worker event queue.
+
+What is different is the DEVICE DISPATCH, redesigned for a 288 GB MI355X:
+  * the slot table never moves.  The reference sorts slots by category with physical swaps of three
+    17 MB state blocks per swap (`_switch_batch`, :304-360) so that a category is a contiguous slice;
+    here every forward takes an int32 ``slot_idx`` vector and the kernels index the pool directly
+    (RWKV_x070.forward_slots).  ``min_swaps_to_target_fast`` is still exported (tested API).
+  * penalties + greedy sampling of all decode rows are one kernel and one D2H copy of B ids
+    (ops.penalize_argmax) instead of ~8 torch kernels and B ``.item()`` syncs (:719-740); rows with
+    real sampling parameters go through samplers.sample_logits_rwkv_pip_compatible.
+  * prefix states exported for the cache are gathered on the device and copied out once.
+"""
+import queue
+import time
+import types
+from collections import deque
+from enum import IntEnum, auto
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .core_structure import ModelLoadConfig, RequestStatus, Task
+from .samplers import is_greedy_row, sample_logits_rwkv_pip_compatible
+
+
+class StateCategory(IntEnum):
+    FORWARD_ONE_DECODE = auto()
+    FORWARD_ONE_PREFILL = auto()
+    FORWARD_ONE_SUSPENDED = auto()
+    FORWARD_SEQ = auto()
+    FINISHED = auto()
+    EMPTY = auto()
+
+
+def min_swaps_to_target_fast(lst, elements):
+    """Partition ``lst`` in place so that equal categories are contiguous in the order of
+    ``elements``; returns (swaps, offsets) like chirrup/worker.py:43-78.  This worker does not need
+    the swaps (it uses slot indices) but the function is part of the reference's tested surface."""
+    swaps: List[Tuple[int, int]] = []
+    offsets: List[Tuple[int, int]] = []
+    lo = 0
+    for cat in elements:
+        here = [i for i in range(lo, len(lst)) if lst[i] == cat]
+        hi = lo + len(here)
+        offsets.append((lo, hi))
+        inside = set(here)
+        holes = [i for i in range(lo, hi) if i not in inside]
+        for hole, src in zip(holes, [i for i in here if i >= hi]):
+            swaps.append((hole, src))
+            lst[hole], lst[src] = lst[src], lst[hole]
+        lo = hi
+    return swaps, offsets
+
+
+def _empty_slot() -> dict:
+    return {"task": None, "is_prefilling": None, "new_token": None, "next_input_token": None,
+            "state_category": StateCategory.EMPTY, "prefilled_tokens": [], "prefill_cached": False, "raw_logits": None}
+
+
+class Worker:
+    def __init__(self, worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, task_queue: queue.Queue,
+                 master_event_queue: queue.Queue, worker_event_queue: Optional[queue.Queue], batch_size: int = 32,
+                 model=None, tokenizer=None, penalize_argmax=None):
+        self.worker_id, self.gpu_id, self.model_config = worker_id, gpu_id, model_config
+        self.task_queue, self.master_event_queue, self.worker_event_queue = task_queue, master_event_queue, worker_event_queue
+        self.real_state_size = batch_size
+        self.max_batch_size = batch_size - 1          # the reference keeps one scratch slot; kept for parity of capacity
+        self.max_prefill_count = max(int(batch_size * 0.125), 1)
+        self.state_slot: Dict[int, dict] = {i: _empty_slot() for i in range(self.max_batch_size)}
+        self.model, self.tokenizer = model, tokenizer   # may be injected (tests use a fake backend)
+        self._penalize_argmax = penalize_argmax if penalize_argmax is not None else ops.penalize_argmax
+        self.batch_state = None
+        self.no_penalty_token_ids = {33, 10, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58}
+        self.min_forward_seq_len = 10
+        self.max_forward_seq_len_per_forward = 100
+        self.seq_forward_count_down = 0
+        self.decode_prefill_ratio = 5
+        self.shutdown_flag = False
+        self.loop_time_recorder = deque(maxlen=10)
+        self.iterations = 0
+
+    # ------------------------------------------------------------------ set-up
+    def _load_model(self):
+        from .rwkv7 import RWKV_x070, model_args
+        from .tokenizer import TRIE_TOKENIZER
+
+        if self.model is None:
+            self.model = RWKV_x070(model_args(self.model_config.model_path, self.model_config.vocab_size,
+                                              self.model_config.head_size))
+        if self.tokenizer is None:
+            self.tokenizer = TRIE_TOKENIZER(self.model_config.vocab_path)
+        self._post({"status": "success", "worker_id": self.worker_id, "gpu_id": self.gpu_id,
+                    "model_path": self.model_config.model_path}, "worker_loaded")
+
+    def _post(self, payload, kind):
+        if self.worker_event_queue is not None:
+            try:
+                self.worker_event_queue.put_nowait((self.worker_id, kind, payload))
+            except queue.Full:      # performance messages are droppable (engine_core.py:42-47)
+                pass
+
+    def _init_worker(self):
+        if self.gpu_id and torch.cuda.is_available():
+            torch.cuda.set_device(self.gpu_id[0])
+        self._load_model()
+        n, V = self.real_state_size, self.model_config.vocab_size
+        self.batch_state = self.model.generate_zero_state(n)
+        dev = self.batch_state[0].device
+        self.device = dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.occurrence = torch.zeros((n, V), **f32)
+        self.alpha_presence_vector = torch.zeros((n, V), **f32)
+        self.temperature_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
+        self.top_p_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
+        self.top_k_tensor = torch.zeros((n, 1), dtype=torch.int32, device=dev)
+        self.frequency_penalty_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
+        self.penalty_decay_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
+        self.presence_penalty_tensor = torch.zeros((n, 1), **f32)
+        self._greedy = [True] * n
+
+    # ------------------------------------------------------------------ per-slot bookkeeping (host only)
+    def _process_events(self) -> bool:
+        while True:
+            try:
+                ev = self.master_event_queue.get_nowait()
+            except queue.Empty:
+                return False
+            if ev.get("type") == "shutdown":
+                self.shutdown_flag = True
+                return True
+
+    @staticmethod
+    def _is_task_aborted(td) -> bool:
+        try:
+            kind, _ = td["task"].task_event_queue.get_nowait()
+            return kind == "abort"
+        except queue.Empty:
+            return False
+
+    def _export_state(self, slot: int):
+        """[state0[:, :, [s]], state1[:, [s]], state2[[s]]] on the CPU (worker.py:426-430)."""
+        s0, s1, s2 = self.batch_state
+        return [s0[:, :, [slot], :].to("cpu", non_blocking=True), s1[:, [slot], :, :].to("cpu", non_blocking=True),
+                s2[[slot]].to("cpu", non_blocking=True)]
+
+    def _maybe_cache_prefill(self, td, slot: int):
+        t: Task = td["task"]
+        if t.cache_prefill and not td["prefill_cached"] and len(t.prefill_tokens) == max(t.cache_prefill_padding - 1, 0):
+            t.output_queue.put_nowait(("cache_prefill", {"state": self._export_state(slot),
+                                                         "prefilled_tokens": tuple(td["prefilled_tokens"])}))
+            td["prefill_cached"] = True
+            return True
+        return False
+
+    def _handle_forward_seq(self, td, slot: int):
+        t: Task = td["task"]
+        if self._maybe_cache_prefill(td, slot):
+            td["state_category"] = StateCategory.FORWARD_ONE_PREFILL
+        if len(t.prefill_tokens) == 0:
+            td["state_category"], td["is_prefilling"] = StateCategory.FORWARD_ONE_DECODE, False
+        elif len(t.prefill_tokens) < self.min_forward_seq_len:
+            td["state_category"] = StateCategory.FORWARD_ONE_PREFILL
+
+    def _handle_forward_one_prefill_phase(self, td, slot: int):
+        t: Task = td["task"]
+        td["prefilled_tokens"].append(td["next_input_token"])
+        td["next_input_token"] = t.prefill_tokens.pop(0)
+        if len(t.prefill_tokens) == 0:
+            td["is_prefilling"], td["state_category"] = False, StateCategory.FORWARD_ONE_DECODE
+        self._maybe_cache_prefill(td, slot)
+
+    def _handle_forward_one_decode_phase(self, td, slot: int):
+        t: Task = td["task"]
+        tok = td["new_token"]
+        if tok in t.stop_tokens:
+            t.request_status = RequestStatus.FINISHED_STOPPED
+            return None
+        text = self.tokenizer.decode([tok], utf8_errors="ignore")
+        t.generated_tokens.append(tok)
+        t.decoded_texts.append(text)
+        if t.return_logits and td["raw_logits"] is not None:
+            t.output_queue.put_nowait(("token_generated", (tok, text, td["raw_logits"])))
+            td["raw_logits"] = None
+        else:
+            t.output_queue.put_nowait(("token_generated", (tok, text)))
+        if len(t.generated_tokens) >= t.max_tokens:
+            t.request_status = RequestStatus.FINISHED_LENGTH_CAPPED
+            return None
+        td["next_input_token"] = tok
+        return slot, tok, 0.0 if tok in self.no_penalty_token_ids else 1.0
+
+    def _batch_update_penalty(self, updates):
+        if not updates:
+            return
+        dev = self.occurrence.device
+        slots = torch.tensor([u[0] for u in updates], device=dev, dtype=torch.long)
+        toks = torch.tensor([u[1] for u in updates], device=dev, dtype=torch.long)
+        wts = torch.tensor([u[2] for u in updates], device=dev, dtype=torch.float32)
+        self.occurrence[slots, toks] += wts
+        self.alpha_presence_vector[slots, toks] = self.presence_penalty_tensor[slots, 0]
+
+    def _process_accomplished_tasks(self, slots):
+        for s in slots:
+            t = self.state_slot[s]["task"]
+            t.output_queue.put_nowait(("task_completed", t))
+            self.state_slot[s] = _empty_slot()
+
+    def _fill_task_pool(self):
+        prefills = 0
+        for slot in range(self.max_batch_size):
+            if prefills >= self.max_prefill_count:
+                break
+            td = self.state_slot[slot]
+            if td["state_category"] != StateCategory.EMPTY:
+                prefills += td["state_category"] == StateCategory.FORWARD_SEQ
+                continue
+            prefills += 1
+            try:
+                task: Task = self.task_queue.get_nowait()
+            except queue.Empty:
+                break
+            self._install(task, slot)
+
+    def _install(self, task: Task, slot: int):
+        s0, s1, s2 = self.batch_state
+        if task.state is None:
+            s0[:, :, slot].zero_(), s1[:, slot].zero_(), s2[slot].zero_()
+        else:                                    # prefix-cache hit: [L,2,1,C], [L,1,H,64,64], [1]
+            s0[:, :, [slot], :] = task.state[0].to(s0.device, non_blocking=True)
+            s1[:, [slot], :, :] = task.state[1].to(s1.device, non_blocking=True)
+            s2[[slot]] = task.state[2].to(s2.device, non_blocking=True)
+        self.occurrence[slot].zero_()
+        self.alpha_presence_vector[slot].zero_()
+        self.temperature_tensor[slot, 0] = task.temperature if task.temperature > 0 else 1.0
+        self.top_p_tensor[slot, 0] = task.top_p
+        self.top_k_tensor[slot, 0] = task.top_k
+        self.frequency_penalty_tensor[slot, 0] = task.frequency_penalty
+        self.penalty_decay_tensor[slot, 0] = task.penalty_decay
+        self.presence_penalty_tensor[slot, 0] = task.presence_penalty
+        self._greedy[slot] = is_greedy_row(task.temperature, task.top_p, task.top_k)
+        first = task.prefill_tokens.pop(0)
+        if len(task.prefill_tokens) == 0:
+            cat, prefilling = StateCategory.FORWARD_ONE_DECODE, False
+        elif len(task.prefill_tokens) - max(task.cache_prefill_padding - 1, 0) < self.min_forward_seq_len:
+            cat, prefilling = StateCategory.FORWARD_ONE_PREFILL, True
+        else:
+            cat, prefilling = StateCategory.FORWARD_SEQ, True
+        td = _empty_slot()
+        td.update(task=task, is_prefilling=prefilling, next_input_token=first, state_category=cat)
+        self.state_slot[slot] = td
+
+    def _organize_batch(self):
+        """Slot ids per category, in slot order (the reference returns contiguous ranges after
+        swapping; here the lists ARE the addressing)."""
+        by_cat: Dict[StateCategory, List[int]] = {c: [] for c in StateCategory}
+        for slot in range(self.max_batch_size):
+            by_cat[self.state_slot[slot]["state_category"]].append(slot)
+        return by_cat
+
+    # ------------------------------------------------------------------ device dispatch
+    def _slot_tensor(self, slots: List[int]) -> torch.Tensor:
+        return torch.tensor(slots, dtype=torch.int32, device=self.device)
+
+    def _run_forward_one(self, decode_slots: List[int], prefill_slots: List[int]):
+        slots = decode_slots + prefill_slots
+        if not slots:
+            return
+        tokens = [[self.state_slot[s]["next_input_token"]] for s in slots]
+        idx = self._slot_tensor(slots)
+        out = self.model.forward_slots(tokens, self.batch_state, idx)
+        nd = len(decode_slots)
+        if nd == 0:
+            return
+        logits = out[:nd]
+        for j, s in enumerate(decode_slots):
+            t: Task = self.state_slot[s]["task"]
+            if t.return_logits:
+                self.state_slot[s]["raw_logits"] = logits[j].clone().detach().cpu()
+            for tok in t.forbidden_tokens:
+                logits[j, tok] -= 1e10
+        didx = idx[:nd]
+        # penalties for every decode row + arg-max, one kernel; occurrence is decayed in place
+        ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
+                                  self.frequency_penalty_tensor.view(-1), didx)
+        sampled = [j for j, s in enumerate(decode_slots) if not self._greedy[s]]
+        if sampled:
+            rows = torch.tensor(sampled, device=self.device, dtype=torch.long)
+            srows = didx.long()[rows]
+            ids[rows] = sample_logits_rwkv_pip_compatible(logits[rows], self.temperature_tensor[srows],
+                                                          self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
+        host_ids = ids.tolist()                  # ONE device->host copy for the whole batch
+        for j, s in enumerate(decode_slots):
+            self.state_slot[s]["new_token"] = int(host_ids[j])
+
+    def _run_forward_seq(self, seq_slots: List[int]):
+        lens = [len(self.state_slot[s]["task"].prefill_tokens) - max(self.state_slot[s]["task"].cache_prefill_padding - 1, 0)
+                for s in seq_slots]
+        n_tok = min(self.max_forward_seq_len_per_forward, *lens)
+        assert n_tok > 0
+        batch = []
+        for s in seq_slots:
+            td = self.state_slot[s]
+            t: Task = td["task"]
+            chunk = [td["next_input_token"]] + t.prefill_tokens[: n_tok - 1]
+            td["prefilled_tokens"].extend(chunk)
+            t.prefill_tokens = t.prefill_tokens[n_tok - 1:]
+            td["next_input_token"] = t.prefill_tokens.pop(0)
+            batch.append(chunk)
+        self.model.forward_slots(batch, self.batch_state, self._slot_tensor(seq_slots))   # logits discarded (:776)
+
+    # ------------------------------------------------------------------ main loop
+    def step(self) -> bool:
+        """One loop iteration (chirrup/worker.py:793-884).  Returns False when idle."""
+        t0 = time.perf_counter()
+        done, updates = [], []
+        for slot in range(self.max_batch_size):
+            td = self.state_slot[slot]
+            cat = td["state_category"]
+            assert cat != StateCategory.FINISHED
+            if cat == StateCategory.EMPTY:
+                continue
+            if self._is_task_aborted(td):
+                td["task"].request_status = RequestStatus.FINISHED_ABORTED
+                td["state_category"] = StateCategory.FINISHED
+            elif cat == StateCategory.FORWARD_SEQ:
+                self._handle_forward_seq(td, slot)
+            elif cat == StateCategory.FORWARD_ONE_PREFILL:
+                self._handle_forward_one_prefill_phase(td, slot)
+            elif cat == StateCategory.FORWARD_ONE_DECODE and td["new_token"] is not None:
+                upd = self._handle_forward_one_decode_phase(td, slot)
+                if upd is not None:
+                    updates.append(upd)
+            if RequestStatus.is_finished(td["task"].request_status):
+                done.append(slot)
+        self._batch_update_penalty(updates)
+        self._process_accomplished_tasks(done)
+        self._fill_task_pool()
+        cats = self._organize_batch()
+        dec, pre, seq = (cats[c] for c in (StateCategory.FORWARD_ONE_DECODE, StateCategory.FORWARD_ONE_PREFILL,
+                                           StateCategory.FORWARD_SEQ))
+        if not dec and not pre and not seq:
+            return False
+        if dec or pre:
+            self._run_forward_one(dec, pre)
+            self.seq_forward_count_down -= 1
+        else:
+            self.seq_forward_count_down = 0
+        if self.seq_forward_count_down < 1 and seq:
+            self._run_forward_seq(seq)
+            self.seq_forward_count_down = max(1, self.decode_prefill_ratio)
+        self.iterations += 1
+        self.loop_time_recorder.append(time.perf_counter() - t0)
+        self._post({"avg_loop_time": sum(self.loop_time_recorder) / len(self.loop_time_recorder),
+                    "state_size": self.real_state_size,
+                    "state_offset_details": {"decode_slots": dec, "one_prefill_slots": pre, "seq_prefill_slots": seq},
+                    "task_details": {"decode_count": len(dec), "one_prefill_count": len(pre), "seq_prefill_count": len(seq)},
+                    "max_allocated_memory_GB": (torch.cuda.max_memory_allocated() / 1024 ** 3) if torch.cuda.is_available() else 0.0},
+                   "worker_performance")
+        return True
+
+    def start(self):
+        if self.batch_state is None:
+            self._init_worker()
+        while True:
+            if self._process_events():
+                break
+            if not self.step():
+                time.sleep(0.05)
+        self._cleanup()
+
+    def _cleanup(self):
+        for name in ("state_slot", "batch_state", "occurrence", "alpha_presence_vector", "model"):
+            if hasattr(self, name):
+                delattr(self, name)
+
+
+def model_load_config_for(model_path: str, vocab_path: str, vocab_size: int = 65536) -> ModelLoadConfig:
+    return ModelLoadConfig(model_path=model_path, vocab_path=vocab_path, vocab_size=vocab_size, head_size=64)
+
+
+__all__ = ["Worker", "StateCategory", "min_swaps_to_target_fast", "types"]

@@ -103,11 +103,12 @@ int mm8_one(int N, int M, const void *x, const void *w, int w_stride, const void
  *   row (t > 0) or prev_in[b] (t == 0), out[m] = cur + (prev - cur) * mix[m], prev_out[b] = cur of
  *   the last row; with n_mix == 0: out = cur.   x,delta,x_out,out[m]: [B][T][C]; prev_*: [B][C];
  *   mix: [n_mix][C]; out planes are out_stride elements apart.  T > 1 needs prev_out != prev_in.
+ *   slot_idx (may be NULL): batch row b carries its token-shift state in row slot_idx[b] of prev_*.
  *   Replaces rwkv7.py:523 + :621-623 (n_mix 6), :531-533 + :675-677 (n_mix 1), :548-550 (n_mix 0).
  */
 int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                      const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
-                     const void *mix, void *out, int64_t out_stride, void *stream);
+                     const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx, void *stream);
 
 /* rwkv7.py:629-637: a = sigmoid(a_pre); kk = normalize(k*k_k) per 64-channel head;
  * k <- k*(1+(a-1)*k_a) in place; neg_kk = -kk; kka = kk*a; and, when v_first != NULL (layer > 0),
@@ -129,6 +130,19 @@ int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems, void *hbuf
 
 /* rwkv7.py:678: x <- relu(x)**2 in place over n elements (n % 8 == 0). */
 int rwkv7_relu_sq(int64_t n, void *x, void *stream);
+
+/*
+ * Penalties + greedy token selection in one pass (rows decoded with temperature 0).
+ * Replaces chirrup/worker.py:724-740 for those rows: occurrence *= decay; logits -= alpha_presence +
+ * occurrence * frequency_penalty (binary32, rounded back into the binary16 logits in place);
+ * ids[row] = argmax (chirrup/utils/samplers.py:195-221 with temperature 0; ties -> lowest id).
+ * logits [B][V] binary16; occurrence, alpha_presence float [n_slots][V]; penalty_decay,
+ * frequency_penalty binary16 [n_slots]; row b uses slot slot_idx[b] (or b).  occurrence == NULL:
+ * arg-max only.  V % 8 == 0.
+ */
+int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const float *alpha_presence,
+                          const void *penalty_decay, const void *frequency_penalty, const int32_t *slot_idx,
+                          int32_t *ids, void *stream);
 
 #ifdef __cplusplus
 }

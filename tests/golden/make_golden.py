@@ -120,6 +120,39 @@ def gen_tokenizer():
     print("wrote tokenizer.json")
 
 
+def gen_tokenizer_mini():
+    """A small synthetic vocabulary in the reference's file format (ids, python literal, byte length)
+    so that the tokenizer can be tested where the real 65k vocabulary file is not available."""
+    from Albatross.utils import TRIE_TOKENIZER
+
+    toks = [bytes([b]) for b in range(1, 128)]                     # single ASCII bytes
+    toks += [w.encode() for w in ("th", "the", "then", "he", "her", "here", " ", "  ", "    ", "\n\n", "ab", "abc", "abcd",
+                                  "bcd", "User", "User:", "Assistant", ":", "ing", "in", "tion", "ti")]
+    toks += ["é".encode(), "中".encode(), "中文".encode(), "😀".encode(), b"\xe4\xb8", b"\xe4", b"\xb8", b"\xad", b"\xc3", b"\xa9",
+             b"\xe6", b"\x96", b"\x87", b"\xf0", b"\x9f", b"\x98", b"\x80"]
+    seen, uniq = set(), []
+    for t in toks:
+        if t not in seen:
+            seen.add(t)
+            uniq.append(t)
+    path = os.path.join(HERE, "mini_vocab.txt")
+    with open(path, "w", encoding="utf-8") as f:
+        for i, t in enumerate(uniq, start=1):
+            try:
+                lit = repr(t.decode("utf-8"))
+            except UnicodeDecodeError:
+                lit = repr(t)
+            f.write(f"{i} {lit} {len(t)}\n")
+    tok = TRIE_TOKENIZER(path)
+    texts = ["the then there her here", "User: abcd abc ab a\n\nAssistant: testing in motion", "中文 中 é 😀 mixed  spaces    x",
+             "", "aaaa", "thetheth"]
+    cases = [{"text": t, "ids": [int(i) for i in tok.encode(t)]} for t in texts]
+    with open(os.path.join(HERE, "tokenizer_mini.json"), "w") as f:
+        json.dump({"source": "Albatross/utils.py:104-159 TRIE_TOKENIZER on tests/golden/mini_vocab.txt (synthetic)",
+                   "cases": cases}, f, ensure_ascii=False)
+    print("wrote mini_vocab.txt / tokenizer_mini.json", len(uniq), "tokens")
+
+
 def gen_mm8():
     sys.path.insert(0, os.path.join(REF, "scripts", "test_mm8"))
     import benchmark_pure_pytorch as bpp  # guarded main(), no compile at import
@@ -276,6 +309,7 @@ if __name__ == "__main__":
     gen_scheduler()
     gen_sampler()
     gen_tokenizer()
+    gen_tokenizer_mini()
     gen_mm8()
     ref = import_reference_model()
     gen_model(ref)
