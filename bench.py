@@ -40,7 +40,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-layers", type=int, default=2, help="layers of the model the CPU baseline times")
+    p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
 
@@ -150,7 +150,6 @@ def main():
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
     tokens = torch.randint(1, 65536, (B, 1), generator=g, device=dev)
-    ids_host = torch.empty((B,), dtype=torch.long).pin_memory()
 
     if a.no_graph:
         step_fn = lambda tok: model.forward_seq_batch(tok, state)
@@ -158,28 +157,27 @@ def main():
         graph = model.capture_decode_graph(state)
         step_fn = graph.step
 
+    from chirrup_amd import ops
+
+    ids_dev = torch.empty((B,), dtype=torch.int32, device=dev)
+    ids_host = torch.empty((B,), dtype=torch.int32).pin_memory()
+
     def one_step(tok):
         logits = step_fn(tok)
-        nxt = logits.argmax(dim=-1)                 # greedy: temperature 0 (samplers.py:195-197)
-        ids_host.copy_(nxt, non_blocking=False)     # the worker needs the ids on the host each step
-        return nxt.view(B, 1)
+        ops.penalize_argmax(logits, out=ids_dev)     # greedy (temperature 0, samplers.py:195-197), penalties 0
+        ids_host.copy_(ids_dev, non_blocking=False)  # the worker needs the ids on the host each step
+        return ids_dev.view(B, 1)
+
+    from chirrup_amd.dist_util import timed_region
+
+    cur = [tokens]
+
+    def timed_step():
+        cur[0] = one_step(cur[0])
 
     for _ in range(a.warmup):
-        tokens = one_step(tokens)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        tokens = one_step(tokens)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        timed_step()
+    dt = timed_region(timed_step, a.steps, dev)       # barrier + sync on both sides, max over ranks
 
     wkv_ms = wkv7_event_timing(model, state, B)
     if rank == 0:
