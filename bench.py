@@ -95,6 +95,30 @@ def wkv7_event_timing(model, state, B, iters=3):
     return sum(ms) / len(ms)
 
 
+def recorded_traffic(B, C):
+    """HBM bytes per WKV7 launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 correction applied) -- only when they were taken at this shape."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*wkv7_pmc_traffic.json")), reverse=True):
+        rec = json.load(open(f))
+        if rec["shape"]["B"] == B and rec["shape"]["C"] == C:
+            return rec["traffic_bytes_per_launch"], os.path.basename(f)
+    return None, None
+
+
+def host_threads():
+    """CPU threads this process may really use (affinity and cgroup quota, not the node's core count)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(name, B, n_layers):
     """The CPU oracle (numpy + C restatement of the reference arithmetic, kind "port") on the host
     cores: `n_layers` layers of the model at the bench batch size + the head GEMM, scaled to L."""
@@ -104,10 +128,14 @@ def cpu_baseline(name, B, n_layers):
     from oracle import native
     from oracle import rwkv7_np as M
 
+    from threadpoolctl import threadpool_limits
+
     native.build()
     L, C = CONFIGS[name]
     V = 65536
-    torch.manual_seed(0)
+    threads = host_threads()
+    torch.set_num_threads(threads)
+    limiter = threadpool_limits(limits=threads)     # numpy BLAS + the oracle's OpenMP loops
     zd = make_state_dict(n_layers, C, V, seed=42)
     z = M.prepare_weights({k_: t.numpy() for k_, t in zd.items()})
     del zd
@@ -124,7 +152,8 @@ def cpu_baseline(name, B, n_layers):
     t_all = time.perf_counter() - t0
     t_layer = max(t_all - t_head, 1e-9) / n_layers
     step = t_layer * L + t_head
-    return {"value": round(B / step, 2), "unit": "tokens/s", "cores": os.cpu_count(), "kind": "port",
+    limiter.restore_original_limits()
+    return {"value": round(B / step, 2), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{n_layers} of {L} layers + head of RWKV7 {name} at bsz {B} (oracle/rwkv7_np.py + oracle.c), "
                       f"{t_all:.1f}s measured, scaled to {L} layers"}
 
@@ -185,6 +214,7 @@ def main():
         value = world * B * a.steps / dt
         bytes_per_launch = B * (270 * C + 4)
         achieved = bytes_per_launch / (wkv_ms * 1e-3) / 1e9
+        traffic, traffic_src = recorded_traffic(B, C)
         weight_bytes = sum(t.numel() * t.element_size() for n, t in model.z.items() if n != "emb.weight")
         step_bytes = weight_bytes + L * bytes_per_launch + B * 65536 * 2
         out = {
@@ -198,7 +228,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "graph": not a.no_graph, "fused_elementwise": not a.no_fused},
             "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "launch_us": round(wkv_ms * 1e3, 2),
                          "launches_per_step": L},
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
