@@ -37,6 +37,21 @@ constexpr float kNexpHalfLog2e = -0.8750387749145276f;
 constexpr float kNlog2e = -1.4426950408889634f;
 constexpr uint32_t kRo1 = 2654435769u;
 
+#ifndef WKV7_LOAD_AUX
+#define WKV7_LOAD_AUX 2       // aux bits of the LDS-DMA state loads: nt (state is touched once per step)
+#endif
+#ifndef WKV7_NT_STORE
+#define WKV7_NT_STORE 1       // non-temporal stores for the updated state (A/B: tools/ab_wkv7.py, +15 % with both)
+#endif
+#ifndef WKV7_MIN_WAVES
+#define WKV7_MIN_WAVES 1      // __launch_bounds__ second argument (waves per SIMD)
+#endif
+#ifndef WKV7_ENTRY_SUFFIX
+#define WKV7_ENTRY_SUFFIX
+#endif
+#define WKV7_CAT2(a, b) a##b
+#define WKV7_CAT(a, b) WKV7_CAT2(a, b)
+
 constexpr int kStateBytes = 64 * 64 * 2;  // one head
 constexpr int kVecBytes = 64 * 2;         // one 64-channel vector
 
@@ -58,7 +73,7 @@ __device__ __forceinline__ f16 decay_term(f16 w_raw, float dither) {
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-__global__ __launch_bounds__(64) void wkv7_seq_kernel(
+__global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const int T, const int C, const int H, f16 *__restrict__ state, const int64_t slot_stride,
     const int32_t *__restrict__ slot_idx, const f16 *__restrict__ r_, const f16 *__restrict__ w_,
     const f16 *__restrict__ k_, const f16 *__restrict__ v_, const f16 *__restrict__ a_,
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(64) void wkv7_seq_kernel(
     for (int q = 0; q < 8; q++) {
         const int row = q * 8 + (lane >> 3);
         const int lch = (lane & 7) ^ ((row >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gptr_t)(gS + row * 128 + lch * 16), (lptr_t)(smem + q * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gS + row * 128 + lch * 16), (lptr_t)(smem + q * 1024), 16, 0, WKV7_LOAD_AUX);
     }
 
     // ---- first timestep's vectors (lane j holds channel j of the head) ----
@@ -163,7 +178,11 @@ __global__ __launch_bounds__(64) void wkv7_seq_kernel(
         const int row = q * 8 + (lane >> 3);
         const int lch = (lane & 7) ^ ((row >> 1) & 7);
         const f16x8 q8 = *reinterpret_cast<const f16x8 *>(smem + q * 1024 + lane * 16);
+#if WKV7_NT_STORE
+        __builtin_nontemporal_store(q8, reinterpret_cast<f16x8 *>(gS + row * 128 + lch * 16));
+#else
         *reinterpret_cast<f16x8 *>(gS + row * 128 + lch * 16) = q8;
+#endif
     }
 }
 
@@ -180,7 +199,7 @@ int check_args(int B, int T, int C, int H, const void *state, const void *r, con
 
 }  // namespace
 
-extern "C" int wkv7_fwd_seq(int B, int T, int C, int H, void *state, const void *r, const void *w,
+extern "C" int WKV7_CAT(wkv7_fwd_seq, WKV7_ENTRY_SUFFIX)(int B, int T, int C, int H, void *state, const void *r, const void *w,
                             const void *k, const void *v, const void *a, const void *b, void *y,
                             const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride,
                             void *stream) {
@@ -194,8 +213,10 @@ extern "C" int wkv7_fwd_seq(int B, int T, int C, int H, void *state, const void 
     return (int)hipGetLastError();
 }
 
+#ifndef WKV7_VARIANT_BUILD
 extern "C" int wkv7_fwd_one(int B, int C, int H, void *state, const void *r, const void *w, const void *k,
                             const void *v, const void *a, const void *b, void *y, const int32_t *elapsed_t,
                             const int32_t *slot_idx, int64_t slot_stride, void *stream) {
     return wkv7_fwd_seq(B, 1, C, H, state, r, w, k, v, a, b, y, elapsed_t, slot_idx, slot_stride, stream);
 }
+#endif
