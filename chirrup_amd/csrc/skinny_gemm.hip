@@ -1,0 +1,394 @@
+// Skinny-M MFMA GEMM for the decode step:  Y[M][N] = X[M][K] . W[N][K]^T   (M <= 256 batch rows)
+// with binary16 or uint8 (mm8) weights, binary32 accumulation.
+//
+// Why a hand-written kernel: at M = 200 the library GEMMs (hipBLASLt through torch) reach only
+// 1.4-2.8 TB/s of weight streaming (profiles/r01_step_v3_*): every 64x64 output tile re-reads its
+// x rows AND its W rows, so each CU ingests far more than its share of W.
+// Here the batch is small enough that ONE workgroup holds all M rows of x for its K-block in LDS:
+//   * workgroup = 4 waves; wave w owns 32 output columns (rows of W) -- W is streamed HBM ->
+//     VGPRs exactly once, 64 contiguous bytes per lane per K-block (full 128-B lines per W row),
+//     never through LDS ("GEMV / M <= 16 decode weights" rule of the CDNA guide, extended to
+//     M <= 256 by sharing x instead of W);
+//   * the x K-block [M][64] is staged once per workgroup through registers into a double-buffered,
+//     XOR-swizzled LDS image (chunk c of row m at m*128 + ((c ^ ((m>>1)&7))<<4): conflict-free
+//     ds_read_b128 for the MFMA B fragments) and reused by all 4 waves; the loads of the next x block
+//     and of the W blocks two steps ahead stay in flight across the barrier (register staging on
+//     purpose: an LDS-DMA in flight would make every barrier a vmcnt(0) drain -- guide section 5);
+//   * v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m): one W fragment
+//     feeds MT = ceil(M/32) MFMAs, so u8 -> f16 conversion (mm8) costs 8 VALU per MT MFMAs;
+//   * optional split-K over blockIdx.y with binary32 partials + a reduce/epilogue kernel
+//     (bias, relu^2, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179).
+// K is consumed in a permuted order inside each 64-block (lane half h takes k = 32h + 8s + j at
+// MFMA step s) -- the same permutation on both operands, so the dot products are unchanged.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chirrup_amd.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+constexpr int kKB = 64;          // K-block
+constexpr int kThreads = 256;    // 4 waves
+constexpr int kBN = 128;         // output columns per workgroup
+
+enum { EPI_F16 = 0, EPI_PARTIAL = 1 };
+
+// two uint8 -> two binary16, exact: bytes b0,b1 -> halves 0x6400|b = 1024 + b, minus 1024
+__device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
+    // v_perm_b32: selector bytes pick from {src0 (hi dword), src1 (lo dword)}; 0x64 bytes come from a constant
+    const uint32_t magic = 0x64646464u;
+    uint32_t r;
+    if (sel_lo)  r = __builtin_amdgcn_perm(magic, packed, 0x04010400u);   // [b1,0x64 | b0,0x64] -> halves (b0),(b1)
+    else         r = __builtin_amdgcn_perm(magic, packed, 0x04030402u);   // bytes 2,3
+    f16x2 v = __builtin_bit_cast(f16x2, r);
+    const f16x2 off = {(f16)1024.f, (f16)1024.f};
+    return v - off;
+}
+
+// Raw weight bytes of one K-block for one lane (k = k0 + 32h .. +32): 64 B (f16) or 32 B (u8).
+template <bool W8>
+struct WRaw {
+    u32x4 q[W8 ? 2 : 4];
+};
+
+template <int MT, bool W8, int EPI>
+__global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
+    const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
+    const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
+    const f16 *__restrict__ bias, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x MT x 4 KiB
+    constexpr int kTileBytes = MT * 32 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = (blockIdx.x * 4 + wave) * 32;
+    const bool wave_live = n0 < N;
+    const int k_begin = blockIdx.y * k_slice;
+    const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
+    const int nkb = (k_end - k_begin) / kKB;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+
+    // x K-block: MT 16-B chunks per lane.  Chunk g = i*256 + tid lands at LDS byte g*16 (linear,
+    // conflict-free ds_write_b128); WHICH chunk of x that is is permuted on the source side so that
+    // chunk c of row m sits at m*128 + ((c ^ ((m>>1)&7))<<4) for the B-fragment reads.
+    const f16 *xsrc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int g = i * kThreads + tid;
+        int m = g >> 3;
+        const int lc = (g & 7) ^ ((m >> 1) & 7);
+        m = m < M ? m : M - 1;
+        xsrc[i] = X + (int64_t)m * ldx + k_begin + lc * 8;
+    }
+    auto load_x = [&](int kb, u32x4 (&xr)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) xr[i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + kb * kKB);
+    };
+    auto store_x = [&](int buf, const u32x4 (&xr)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) *reinterpret_cast<u32x4 *>(smem + buf * kTileBytes + (i * kThreads + tid) * 16) = xr[i];
+    };
+    const int n_row = (n0 + r) < N ? (n0 + r) : (N - 1);
+    const unsigned char *wrow = static_cast<const unsigned char *>(Wv) + ((int64_t)n_row * ldw + k_begin + 32 * h) * (W8 ? 1 : 2);
+    auto load_w = [&](int kb, WRaw<W8> &w) {
+        const u32x4 *p = reinterpret_cast<const u32x4 *>(wrow + (int64_t)kb * kKB * (W8 ? 1 : 2));
+#pragma unroll
+        for (int i = 0; i < (W8 ? 2 : 4); i++) w.q[i] = p[i];
+    };
+
+    auto compute = [&](int buf, const WRaw<W8> &w) {
+        f16x8 wf[4];
+        if constexpr (W8) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const uint32_t lo = w.q[s >> 1][2 * (s & 1)], hi = w.q[s >> 1][2 * (s & 1) + 1];
+                const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
+                wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) wf[s] = __builtin_bit_cast(f16x8, w.q[s]);
+        }
+        const unsigned char *xt = smem + buf * kTileBytes;
+        auto bfrag = [&](int s, int mt) {
+            const int m = mt * 32 + r;
+            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
+        };
+        // B fragments one MFMA group ahead of their use (two register sets of MT fragments)
+        f16x8 b0[MT], b1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(0, mt);
+#pragma unroll
+        for (int s = 0; s < 4; s += 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) b1[mt] = bfrag(s + 1, mt);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b0[mt], acc[mt], 0, 0, 0);
+            if (s + 2 < 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(s + 2, mt);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s + 1], b1[mt], acc[mt], 0, 0, 0);
+        }
+    };
+
+    // Everything is visible to hipcc (no LDS-DMA, no asm): its counted vmcnt waits keep the W loads
+    // of the next two K-blocks and the x loads of the next one in flight across __syncthreads()
+    // (a plain s_barrier when no LDS-DMA is pending).
+    WRaw<W8> w0, w1, w2;
+    u32x4 xr[MT];
+    if (nkb > 0) {
+        load_x(0, xr);
+        load_w(0, w0);
+        if (nkb > 1) load_w(1, w1);
+        store_x(0, xr);
+    }
+    __syncthreads();
+#define SKINNY_STEP(KB, WCUR, WNEXT2)                                   \
+    if ((KB) < nkb) {                                                   \
+        const bool more = (KB) + 1 < nkb;                               \
+        if (more) load_x((KB) + 1, xr);                                 \
+        if ((KB) + 2 < nkb) load_w((KB) + 2, WNEXT2);                   \
+        compute((KB) & 1, WCUR);                                        \
+        if (more) store_x(((KB) + 1) & 1, xr);                          \
+        __syncthreads();                                                \
+    }
+    for (int kb = 0; kb < nkb; kb += 3) {
+        SKINNY_STEP(kb, w0, w2)
+        SKINNY_STEP(kb + 1, w1, w0)
+        SKINNY_STEP(kb + 2, w2, w1)
+    }
+#undef SKINNY_STEP
+
+    if (!wave_live) return;
+    // acc[mt][i]: m = mt*32 + (lane & 31), n = n0 + 8*(i>>2) + 4*h + (i&3)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int m = mt * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + 8 * g + 4 * h;
+            if (n >= N) continue;
+            if (EPI == EPI_F16) {
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = acc[mt][4 * g + e];
+                    if (bias) v += (float)bias[n + e];
+                    o[e] = (f16)v;
+                }
+                *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+            } else {
+                const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(part + ((int64_t)blockIdx.y * M + m) * N + n) = o;
+            }
+        }
+    }
+}
+
+// Sum the split-K partials and apply the epilogue.
+//   mode 0: y = sum (+ bias[n]);  mode 1: y = relu(sum (+bias))^2;
+//   mode 2 (mm8): y = rx[n]*(sum + 0.5*S[m][0]) + S[m][1] + mx[n]*S[m][2]      (benchmark.py:167-179)
+//   mode 3: mm8 then relu^2
+__global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const int N, const int splits,
+                                                            const float *__restrict__ part, const f16 *__restrict__ bias,
+                                                            const f16 *__restrict__ rx, const f16 *__restrict__ mx,
+                                                            const float *__restrict__ S, const int mode,
+                                                            f16 *__restrict__ Y, const int ldy) {
+    const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)M * N / 4;
+    if (gi >= total) return;
+    const int m = (int)(gi / (N / 4)), n = (int)(gi % (N / 4)) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N + n);
+    f16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        float v = s[e];
+        if (mode >= 2) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
+        else if (bias) v += (float)bias[n + e];
+        if (mode == 1 || mode == 3) {
+            v = (float)(f16)v;                       // relu(fp16(y))**2, rwkv7.py:678
+            v = v > 0.f ? v * v : 0.f;
+        }
+        o[e] = (f16)v;
+    }
+    *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+}
+
+// mm8 activation prologue: xs = fp16(x * ry), S[m] = {sum xs, sum x*my, sum x}   (benchmark.py:167-173)
+__global__ __launch_bounds__(256) void mm8_prep_kernel(const int K, const f16 *__restrict__ x, const int ldx,
+                                                       const f16 *__restrict__ ry, const f16 *__restrict__ my,
+                                                       f16 *__restrict__ xs, float *__restrict__ S) {
+    __shared__ float red[3][4];
+    const int m = blockIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int c = threadIdx.x * 8; c < K; c += 256 * 8) {
+        const f16x8 xv = *reinterpret_cast<const f16x8 *>(x + (int64_t)m * ldx + c);
+        const f16x8 rv = *reinterpret_cast<const f16x8 *>(ry + c);
+        const f16x8 mv = *reinterpret_cast<const f16x8 *>(my + c);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            o[e] = (f16)((float)xv[e] * (float)rv[e]);
+            s0 += (float)o[e];
+            s1 += (float)xv[e] * (float)mv[e];
+            s2 += (float)xv[e];
+        }
+        *reinterpret_cast<f16x8 *>(xs + (int64_t)m * K + c) = o;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s0 += __shfl_xor(s0, o, 64);
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0;
+        red[1][threadIdx.x >> 6] = s1;
+        red[2][threadIdx.x >> 6] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) S[m * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+template <bool W8>
+int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X,
+           int ldx, const void *W, int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+#define GO(MTV)                                                                                                              \
+    do {                                                                                                                     \
+        if (lds > 65536) {                                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>),                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_F16>),                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
+        }                                                                                                                    \
+        if (partial)                                                                                                         \
+            hipLaunchKernelGGL((skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X, \
+                               ldx, W, ldw, Y, ldy, bias, part);                                                             \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((skinny_gemm_kernel<MTV, W8, EPI_F16>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X,    \
+                               ldx, W, ldw, Y, ldy, bias, part);                                                             \
+    } while (0)
+    switch (MT) {
+        case 1: GO(1); break;
+        case 2: GO(2); break;
+        case 3: GO(3); break;
+        case 4: GO(4); break;
+        case 5: GO(5); break;
+        case 6: GO(6); break;
+        case 7: GO(7); break;
+        default: GO(8); break;
+    }
+#undef GO
+    return (int)hipGetLastError();
+}
+
+int pick_splits(int N, int K, int requested) {
+    if (requested > 0) return requested;
+    const int ngroups = (N + kBN - 1) / kBN;
+    int s = (256 + ngroups - 1) / ngroups;             // aim at >= 256 workgroups
+    const int max_s = K / 256 > 0 ? K / 256 : 1;       // keep >= 4 K-blocks per slice
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    while (s > 1 && (K / kKB) % s) s--;                // slices of whole K-blocks, equal size
+    return s;
+}
+
+}  // namespace
+
+extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int s = pick_splits(N, K, splits);
+    return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
+// Y = act(X . W^T + bias);  W binary16 [N][K] (row stride ldw).  act: 0 none, 1 relu^2.
+extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
+                               void *Y, int ldy, int act, int splits, void *workspace, void *stream) {
+    if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N || (ldx & 7) || (ldw & 7) || (ldy & 3))
+        return CHIRRUP_E_SHAPE;
+    if (!X || !W || !Y) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
+        return CHIRRUP_E_ALIGN;
+    const int s = pick_splits(N, K, splits);
+    const bool partial = s > 1 || act != 0;
+    if (partial && !workspace) return CHIRRUP_E_NULL;
+    const int MT = (M + 31) / 32;
+    const int k_slice = K / s;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((N + kBN - 1) / kBN, s);
+    const size_t lds = (size_t)2 * MT * 32 * 128;
+    int rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                           (const f16 *)bias, (float *)workspace);
+    if (rc) return rc;
+    if (partial) {
+        const int64_t total = (int64_t)M * N / 4;
+        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, s,
+                           (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr, act ? 1 : 0, (f16 *)Y, ldy);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}
+
+// mm8 with K-contiguous ("packed", [M_out][N_in]) uint8 weights.  Same quantisation and formula as
+// mm8_seq; evaluated in the split form: xs = fp16(x*ry) through MFMA, rank-1 corrections after.
+// workspace layout: xs [B][N_in] f16 | S [B][3] f32 | partials [splits][B][M_out] f32
+extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) {
+    if (B <= 0 || N_in <= 0 || M_out <= 0) return 0;
+    const int s = pick_splits(M_out, N_in, splits);
+    int64_t b = (int64_t)B * N_in * 2;
+    b = (b + 255) / 256 * 256;
+    b += 256 * ((B * 3 * 4 + 255) / 256);
+    b += (int64_t)s * B * M_out * 4;
+    return b;
+}
+
+extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,
+                        const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
+                        int splits, void *workspace, void *stream) {
+    if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
+        y_stride < M_out || (x_stride & 7) || (w_stride & 15) || (y_stride & 3))
+        return CHIRRUP_E_SHAPE;
+    if (!x || !wT || !mx || !rx || !my || !ry || !y || !workspace) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wT) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
+        return CHIRRUP_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int s = pick_splits(M_out, N_in, splits);
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    f16 *xs = reinterpret_cast<f16 *>(ws);
+    int64_t off = ((int64_t)B * N_in * 2 + 255) / 256 * 256;
+    float *S = reinterpret_cast<float *>(ws + off);
+    off += 256 * ((B * 3 * 4 + 255) / 256);
+    float *part = reinterpret_cast<float *>(ws + off);
+    hipLaunchKernelGGL(mm8_prep_kernel, dim3(B), dim3(256), 0, st, N_in, (const f16 *)x, x_stride, (const f16 *)ry,
+                       (const f16 *)my, xs, S);
+    const int MT = (B + 31) / 32;
+    const dim3 grid((M_out + kBN - 1) / kBN, s);
+    const size_t lds = (size_t)2 * MT * 32 * 128;
+    int rc = launch<true>(MT, true, grid, lds, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, (f16 *)y, y_stride,
+                          nullptr, part);
+    if (rc) return rc;
+    const int64_t total = (int64_t)B * M_out / 4;
+    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, M_out, s, part,
+                       nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2, (f16 *)y, y_stride);
+    return (int)hipGetLastError();
+}

@@ -236,6 +236,51 @@ def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=
     return out
 
 
+def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
+    """y = act(x @ weight.T + bias) through the hand-written skinny-M MFMA GEMM (x [M<=256, K] fp16,
+    weight [N, K] fp16 row-major, may be a row-strided view).  act 1 = relu(.)**2."""
+    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+        raise _lib.ChirrupAmdError("skinny_linear: expected x [M,K], weight [N,K]")
+    for name, t in (("x", x), ("weight", weight)):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(1) != 1:
+            raise _lib.ChirrupAmdError(f"{name}: expected GPU fp16 with unit inner stride")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=x.device)
+    L = _lib.load()
+    nbytes = L.skinny_gemm_workspace_bytes(M, N, K, splits)
+    if act and nbytes == 0:
+        nbytes = M * N * 4
+    ws = _workspace(nbytes, x.device) if nbytes else None
+    if bias is not None:
+        _chk16("bias", bias, N)
+    rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias),
+                           out.data_ptr(), out.stride(0), act, splits, _ptr(ws), _stream())
+    _lib.check(rc, "skinny_gemm_f16")
+    return out
+
+
+def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None):
+    """mm8 with K-contiguous uint8 weights wT [M_out, N_in] (see include/chirrup_amd.h: mm8t_seq)."""
+    B, N = x.shape
+    M = wT.shape[0]
+    if not wT.is_cuda or wT.dtype != torch.uint8 or wT.shape[1] != N or wT.stride(1) != 1:
+        raise _lib.ChirrupAmdError("wT: expected GPU uint8 [M_out, N_in] with unit inner stride")
+    if not x.is_cuda or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise _lib.ChirrupAmdError("x: expected GPU fp16 with unit inner stride")
+    _chk16("mx", mx, M), _chk16("rx", rx, M), _chk16("my", my, N), _chk16("ry", ry, N)
+    if out is None:
+        out = torch.empty((B, M), dtype=torch.float16, device=x.device)
+    L = _lib.load()
+    ws = _workspace(L.mm8t_workspace_bytes(B, N, M, splits) + 256, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    rc = L.mm8t_seq(B, N, M, x.data_ptr(), x.stride(0), wT.data_ptr(), wT.stride(0), mx.data_ptr(), rx.data_ptr(),
+                    my.data_ptr(), ry.data_ptr(), out.data_ptr(), out.stride(0), act, splits, base, _stream())
+    _lib.check(rc, "mm8t_seq")
+    return out
+
+
 def lora_act_(hbuf, first_plane: int) -> None:
     """hbuf [n, rows, D] fp16, planes first_plane.. of [v, w, a, g]: tanh on w, sigmoid on g."""
     _chk16("hbuf", hbuf)

@@ -145,6 +145,10 @@ class RWKV_x070:
         self.fused = fused and self.device.type == "cuda"
         self._wkv = wkv_impl if wkv_impl is not None else ops.forward_seq
         self._layers = [_Layer(self.z, i) for i in range(self.n_layer)] if auto_load else []
+        # the LoRA chain (2 small batched GEMMs + activation) is independent of the R/K/V GEMM: it runs
+        # on a side stream, forked and joined with events (capturable in the decode graph)
+        self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
+        self.overlap_lora = True
         if self.fused:
             for i, lw in enumerate(self._layers):
                 lw.pack_for_fused(self.z, i)
@@ -335,12 +339,20 @@ class RWKV_x070:
             if T > 1:
                 commit_carry(prev)
             # planes: 0 r, 1 k, 2 v, 3 w, 4 a, 5 g
-            rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))            # one launch for R, K, V
-            r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
             p0 = 1 if i == 0 else 0                                                           # layer 0 has no v gate
-            hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
-            ops.lora_act_(hid, p0)                                                            # tanh(w), sigmoid(g)
-            up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))             # + v0 / w0 / a0 / 0
+            main = torch.cuda.current_stream()
+            side = self._side if self.overlap_lora else None
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
+                ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
+                up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))         # + v0 / w0 / a0 / 0
+            rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))            # one launch for R, K, V
+            if side is not None:
+                main.wait_stream(side)
+                hid.record_stream(main), up.record_stream(main)
+            r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
             vg_pre = up[0].view(B, T, C) if i > 0 else None
             w, a_pre, g = (up[j - p0].view(B, T, C) for j in (1, 2, 3))
             ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)

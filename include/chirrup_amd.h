@@ -132,6 +132,33 @@ int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems, void *hbuf
 int rwkv7_relu_sq(int64_t n, void *x, void *stream);
 
 /*
+ * Skinny-M MFMA GEMM for the decode step: Y[M][N] = act(X[M][K] . W[N][K]^T + bias), M <= 256,
+ * binary16 in / binary32 accumulate / binary16 out.  Plays the role of the reference's
+ * F.linear / torch.matmul calls on the projection weights (Albatross/rwkv7.py:625-630, :649, :678-679,
+ * :551) for batch sizes where the library GEMM is operand-ingest bound.
+ * W row-major [N][K] (the layout the reference keeps its `*.weight` tensors in), row stride ldw
+ * elements; K % 64 == 0, N % 4 == 0, ldx % 8 == 0, ldw % 8 == 0.  act: 0 none, 1 relu(.)^2 (rwkv7.py:678).
+ * splits: K-split factor (0 = choose); needs skinny_gemm_workspace_bytes(M,N,K,splits) bytes of
+ * device scratch when that is > 0 or act != 0.
+ */
+int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
+int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
+                    void *Y, int ldy, int act, int splits, void *workspace, void *stream);
+
+/*
+ * mm8 (w8a16) on the matrix cores: same quantisation and result as mm8_seq, but the uint8 weights
+ * are given K-CONTIGUOUS, wT[M_out][N_in] (the transpose of the reference's w[N_in][M_out]; weights
+ * are static, the transpose is done once at load).  Evaluated in the reference's algebraically split
+ * form (scripts/test_mm8/benchmark.py:167-179): xs = fp16(x*ry) through MFMA against the exact
+ * uint8->binary16 weights, then y = rx*(acc + 0.5*sum xs) + sum x*my + mx*sum x.  act as above.
+ * Replaces the tiled / WMMA variants scripts/test_mm8/rwkv_pip_operators.cu:205-558 (B <= 256).
+ */
+int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits);
+int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,
+             const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
+             int splits, void *workspace, void *stream);
+
+/*
  * Penalties + greedy token selection in one pass (rows decoded with temperature 0).
  * Replaces chirrup/worker.py:724-740 for those rows: occurrence *= decay; logits -= alpha_presence +
  * occurrence * frequency_penalty (binary32, rounded back into the binary16 logits in place);

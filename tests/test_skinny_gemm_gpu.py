@@ -1,0 +1,69 @@
+"""Skinny-M MFMA GEMM (fp16 and mm8/u8 weights) against fp64 math and the mm8 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rwkv7_np as M_
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, bias=None):
+    y = x.double() @ w.double().t()
+    if bias is not None:
+        y = y + bias.double()
+    return y
+
+
+@pytest.mark.parametrize("M,N,K,splits,bias,act", [
+    (1, 128, 64, 1, False, 0), (7, 96, 128, 1, True, 0), (33, 480, 4096, 0, True, 0), (200, 4096, 4096, 0, False, 0),
+    (200, 4096, 4096, 1, False, 0), (200, 16384, 4096, 0, False, 1), (200, 4096, 16384, 8, False, 0),
+    (256, 132, 192, 3, True, 1), (64, 4096, 128, 1, True, 0), (200, 4096, 480 + 32, 0, True, 0)])
+def test_skinny_linear_matches_fp64(M, N, K, splits, bias, act):
+    from chirrup_amd import ops
+
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda").half() if bias else None
+    y = ops.skinny_linear(x, w, b, act=act, splits=splits)
+    want = _ref(x, w, b)
+    if act:
+        want = torch.relu(want.half().double()) ** 2
+    err = (y.double() - want).abs()
+    # fp16 output rounding (+ fp32 accumulation); relu^2 doubles the relative error of its fp16 input
+    tol = (4e-3 if act else 2e-3) * want.abs().clamp_min(1.0)
+    assert bool((err <= tol).all()), float((err / want.abs().clamp_min(1.0)).max())
+    # row-strided views (the model passes planes of packed tensors)
+    wbig = torch.zeros(N, K + 64, device="cuda", dtype=torch.float16)
+    wbig[:, :K] = w
+    y2 = ops.skinny_linear(x, wbig[:, :K], b, act=act, splits=splits)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("B,N,M,splits,act", [(4, 256, 512, 1, 0), (3, 512, 128, 2, 0), (200, 4096, 1024, 0, 0),
+                                              (200, 1024, 4096, 0, 1), (33, 320, 700 // 4 * 4, 1, 0)])
+def test_mm8t_matches_oracle(oracle, B, N, M, splits, act):
+    """MFMA mm8 vs the as-coded oracle.  The split form rounds xs = x*ry to fp16 once (the reference's
+    own Albatross decomposition does the same, benchmark.py:167), so the bar is the reference's stated
+    rtol 1e-3 against the row scale, not bit equality."""
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(B + N + M)
+    x = rng.standard_normal((B, N)).astype(np.float16)
+    w16 = (rng.standard_normal((N, M)) / np.sqrt(N)).astype(np.float16)
+    q, mx, rx, my, ry = M_.quantize_weight(w16)
+    want = oracle.mm8_seq(x, q, mx, rx, my, ry).astype(np.float32)
+    if act:
+        want = np.maximum(want.astype(np.float16).astype(np.float32), 0) ** 2
+    qT = np.ascontiguousarray(q.T)
+    y = ops.mm8t_linear(torch.from_numpy(x).cuda(), torch.from_numpy(qT).cuda(), torch.from_numpy(mx).cuda(),
+                        torch.from_numpy(rx).cuda(), torch.from_numpy(my.reshape(-1)).cuda(),
+                        torch.from_numpy(ry.reshape(-1)).cuda(), act=act, splits=splits)
+    got = y.cpu().numpy().astype(np.float32)
+    scale = np.abs(want).max()
+    assert np.allclose(got, want, rtol=2e-3, atol=2e-3 * scale), float(np.abs(got - want).max() / scale)
+    # and the dequantised weights really approximate the fp16 matrix (quantisation error ~ 1/256 of the range)
+    dense = x.astype(np.float32) @ w16.astype(np.float32)
+    if not act:
+        assert np.abs(got - dense).max() <= 0.05 * np.abs(dense).max()
