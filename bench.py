@@ -39,18 +39,20 @@ def parse():
     p.add_argument("--bsz", type=int, default=200)
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
+    p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
 
-def build_model(name, device, fused):
+def build_model(name, device, fused, mm8=False):
     from chirrup_amd.rwkv7 import RWKV_x070, model_args
     from chirrup_amd.synth import CONFIGS, make_state_dict
 
     L, C = CONFIGS[name]
     zd = make_state_dict(L, C, 65536, seed=42, device=device)      # random-init weights of the architecture
-    m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused)
+    m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused,
+                  ffn_dtype=torch.int8 if mm8 else torch.float16)
     del zd
     torch.cuda.empty_cache()
     return m
@@ -174,7 +176,7 @@ def main():
 
     L, C = CONFIGS[a.model]
     B = a.bsz
-    model = build_model(a.model, dev, fused=not a.no_fused)
+    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8)
     state = make_state(model, B)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -215,13 +217,16 @@ def main():
         bytes_per_launch = B * (270 * C + 4)
         achieved = bytes_per_launch / (wkv_ms * 1e-3) / 1e9
         traffic, traffic_src = recorded_traffic(B, C)
-        weight_bytes = sum(t.numel() * t.element_size() for n, t in model.z.items() if n != "emb.weight")
+        weight_bytes = 0
+        for n, t in model.z.items():
+            if n != "emb.weight":
+                weight_bytes += sum(x.numel() * x.element_size() for x in (t if isinstance(t, tuple) else (t,)))
         step_bytes = weight_bytes + L * bytes_per_launch + B * 65536 * 2
         out = {
             "metric": "decode tokens/sec (whole job) and tps/request, RWKV7-g1 " + a.model + f" bsz={B}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
+            "dtype": "f16" if not a.mm8 else "f16 (u8 ffn weights, mm8)", "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
                                    "greedy decode step incl. sampling and token-id D2H; random-init weights",

@@ -76,7 +76,7 @@ class _Layer:
 
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
-                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias")
+                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias", "f_K8", "f_V8")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -122,13 +122,26 @@ class _Layer:
                 setattr(self, "v" + sfx, z[a + "a" + sfx])
         self.lbias = torch.stack([self.v0, self.w0, self.a0, torch.zeros_like(self.a0)]).view(4, 1, C).contiguous()
 
+    def quantize_ffn(self, z, i):
+        """mm8 (w8a16) channel-mix: quantise ffn.key / ffn.value like the reference's quantize_weight
+        (scripts/test_mm8/benchmark.py:54-85, matrices named at :447-452) and drop the fp16 copies.
+        z keeps '<key>.mm8' -> Mm8Weight instead of the fp16 tensor."""
+        from .quant import quantize_linear
+
+        f = f"blocks.{i}.ffn."
+        self.f_K8 = quantize_linear(self.f_K)                 # Linear weight [4C, C]
+        self.f_V8 = quantize_linear(self.f_V.t())             # f_V is the [4C, C] view of the [C, 4C] Linear weight
+        z[f + "key.weight.mm8"], z[f + "value.weight.mm8"] = self.f_K8, self.f_V8
+        del z[f + "key.weight"], z[f + "value.weight"]
+        self.f_K = self.f_V = None
+
 
 class RWKV_x070:
     """See module docstring.  ``wkv_impl`` is a test hook (signature of ops.forward_seq); the
     default is the HIP kernel and nothing else is ever selected automatically."""
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
-                 fused: bool = True, wkv_impl: Optional[Callable] = None):
+                 fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16):
         self.args = args
         args.head_size = HEAD_SIZE
         if device is None:
@@ -149,9 +162,16 @@ class RWKV_x070:
         # on a side stream, forked and joined with events (capturable in the decode graph)
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
+        self.ffn_dtype = ffn_dtype
+        if ffn_dtype not in (torch.float16, torch.int8):
+            raise ValueError("ffn_dtype must be torch.float16 or torch.int8 (mm8, w8a16)")
+        if ffn_dtype == torch.int8 and not self.fused:
+            raise ops._lib.ChirrupAmdError("the mm8 channel-mix path needs the HIP kernels (a GPU, fused=True)")
         if self.fused:
             for i, lw in enumerate(self._layers):
                 lw.pack_for_fused(self.z, i)
+                if ffn_dtype == torch.int8:
+                    lw.quantize_ffn(self.z, i)
             torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ reference surface
@@ -169,7 +189,13 @@ class RWKV_x070:
     def get_gpu_parameter_groups(self, print_details: bool = False):
         """[{size, keys}] for pre / each layer / post (Albatross/rwkv7.py:384-500)."""
         z = self.z
-        nbytes = lambda keys: sum(z[k].numel() * z[k].element_size() for k in keys)
+        def nbytes(keys):
+            tot = 0
+            for k in keys:
+                t = z[k] if k in z else z[k + ".mm8"]
+                tot += sum(x.numel() * x.element_size() for x in (t if isinstance(t, tuple) else (t,)))
+            return tot
+
         groups = []
         pre = ["emb.weight", "blocks.0.ln0.weight", "blocks.0.ln0.bias"]
         groups.append({"size": nbytes(pre), "keys": pre})
@@ -369,9 +395,13 @@ class RWKV_x070:
                            lw.f_x_k.view(1, C), kin, slot_idx)
             if T > 1:
                 commit_carry(prev)
-            kf = F.linear(kin[0], lw.f_K)
-            ops.relu_sq_(kf)
-            delta = kf @ lw.f_V
+            if self.ffn_dtype == torch.int8:        # mm8 on the matrix cores, relu^2 fused into the epilogue
+                kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1)
+                delta = ops.mm8t_linear(kf, *lw.f_V8).view(B, T, C)
+            else:
+                kf = F.linear(kin[0], lw.f_K)
+                ops.relu_sq_(kf)
+                delta = kf @ lw.f_V
         if T > 1 and not full_output:
             x, delta, rows_out = x[:, -1, :].contiguous(), delta[:, -1, :].contiguous(), (B, 1)
         else:

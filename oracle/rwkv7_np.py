@@ -128,7 +128,29 @@ def cmix(x, x_prev, x_k, K_, V_):
     return matmul_f16(k, V_)
 
 
-def forward_seq_batch(z, tokens, state, n_layer, full_output=False):
+def cmix_mm8(x, x_prev, x_k, K8, V8):
+    """Channel-mix with the two matmuls through mm8 (w8a16): same token shift and relu^2 as cmix,
+    the products evaluated by the as-coded mm8 kernel restatement (oracle.c: oracle_mm8_seq, following
+    scripts/test_mm8/rwkv_pip_operators.cu:59-83).  K8 / V8 = (q [N,M], mx, rx, my, ry)."""
+    B, T, C = x.shape
+    xx = _shift(x, x_prev[1])
+    x_prev[1] = x[:, -1, :]
+    k = (x + xx * x_k).reshape(B * T, C)
+    k = np.maximum(native.mm8_seq(k, *K8), F16(0))
+    k = k * k
+    return native.mm8_seq(k, *V8).reshape(B, T, C)
+
+
+def quantize_ffn(z, n_layer):
+    """{layer: (K8, V8)} for the mm8 path; matrices in the orientation they multiply with."""
+    out = {}
+    for i in range(n_layer):
+        f = f"blocks.{i}.ffn."
+        out[i] = (quantize_weight(z[f + "key.weight"].T), quantize_weight(z[f + "value.weight"]))
+    return out
+
+
+def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None):
     """forward_seq_batch_seperate = _pre/_layers/_post, Albatross/rwkv7.py:503-563.
     tokens [B][T] ints (equal lengths); state = [s0 [L,2,B,C], s1 [L,B,H,64,64], s2 [B] int32],
     all numpy, updated IN PLACE.  Returns logits f16 [B,V] (or [B,T,V])."""
@@ -145,7 +167,10 @@ def forward_seq_batch(z, tokens, state, n_layer, full_output=False):
         xx, v_first = tmix(i, H, xx, s0[i], v_first, s1[i], z, att, s2)
         x = x + xx
         xx = layer_norm(x, z[bbb + "ln2.weight"], z[bbb + "ln2.bias"])
-        xx = cmix(xx, s0[i], z[ffn + "x_k"], z[ffn + "key.weight"], z[ffn + "value.weight"])
+        if mm8 is not None:
+            xx = cmix_mm8(xx, s0[i], z[ffn + "x_k"], *mm8[i])
+        else:
+            xx = cmix(xx, s0[i], z[ffn + "x_k"], z[ffn + "key.weight"], z[ffn + "value.weight"])
         x = x + xx
     if not full_output:
         x = x[:, -1, :]

@@ -127,3 +127,35 @@ def test_larger_config_vs_numpy_oracle(oracle):
             assert e_s1 <= min(5e-3, 2 * floor_s1 + 5e-4), (step, f, e_s1, floor_s1)
             assert states[f][2].tolist() == st_np[2].tolist()
         tokens = [[int(t)] for t in lg_np.astype(F32).argmax(-1)]
+
+
+def test_mm8_channel_mix_model_vs_oracle(oracle):
+    """ModelLoadConfig(dtype=int8) path: ffn.key / ffn.value quantised like the reference's
+    quantize_weight and multiplied by the MFMA mm8 kernel.  Checked against the numpy oracle with the
+    SAME quantised weights (as-coded mm8 arithmetic, oracle_mm8_seq), and against the fp16 model to
+    show the quantisation error is what w8 costs (a few percent of the logit scale), not a bug."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from oracle import rwkv7_np as M
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    z_np = M.prepare_weights({k[2:]: d[k] for k in d.files if k.startswith("w:")})
+    mm8 = M.quantize_ffn(z_np, 2)
+    args = lambda: types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
+    m8 = RWKV_x070(args(), state_dict=zd, device="cuda:0", ffn_dtype=torch.int8)
+    m16 = RWKV_x070(args(), state_dict=zd, device="cuda:0")
+    assert "blocks.0.ffn.key.weight" not in m8.z and m8.z["blocks.0.ffn.key.weight.mm8"].qT.dtype == torch.uint8
+    assert np.array_equal(m8.z["blocks.1.ffn.value.weight.mm8"].qT.t().cpu().numpy(), mm8[1][1][0])   # same bytes as the oracle's
+    for tag in ("b3t1", "b3t5"):
+        st_np = [d[f"{tag}:{n}_in"].copy() for n in ("s0", "s1", "s2")]
+        lg_np = M.forward_seq_batch(z_np, d[f"{tag}:tokens"].tolist(), st_np, 2, mm8=mm8)
+        st8 = [torch.from_numpy(d[f"{tag}:{n}_in"].copy()).cuda() for n in ("s0", "s1", "s2")]
+        st16 = [t.clone() for t in st8]
+        lg8 = m8.forward_seq_batch_seperate(d[f"{tag}:tokens"].tolist(), st8)
+        lg16 = m16.forward_seq_batch_seperate(d[f"{tag}:tokens"].tolist(), st16)
+        # the split form rounds xs = x*ry to fp16 (the reference's own decomposition does), so a little
+        # more noise than the fp16 path: 4e-3 of the logit scale vs the oracle
+        assert rel_linf(lg8.cpu().numpy(), lg_np) <= 4e-3
+        assert rel_linf(st8[1].cpu().numpy(), st_np[1]) <= 2e-3
+        q_err = rel_linf(lg8.cpu().numpy(), lg16.cpu().numpy())
+        assert 1e-4 < q_err < 0.08, q_err
