@@ -76,7 +76,7 @@ class _Layer:
 
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
-                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias", "f_K8", "f_V8")
+                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias", "f_K8", "f_V8", "f_V_rows")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -141,7 +141,8 @@ class RWKV_x070:
     default is the HIP kernel and nothing else is ever selected automatically."""
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
-                 fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16):
+                 fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16,
+                 sparse_bsz1: bool = False):
         self.args = args
         args.head_size = HEAD_SIZE
         if device is None:
@@ -163,6 +164,10 @@ class RWKV_x070:
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
         self.ffn_dtype = ffn_dtype
+        # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
+        # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
+        # keeps one extra copy of ffn.value per layer -- meant for the small single-stream configs
+        self.sparse_bsz1 = bool(sparse_bsz1) and fused and self.device.type == "cuda" and ffn_dtype == torch.float16
         if ffn_dtype not in (torch.float16, torch.int8):
             raise ValueError("ffn_dtype must be torch.float16 or torch.int8 (mm8, w8a16)")
         if ffn_dtype == torch.int8 and not self.fused:
@@ -172,6 +177,7 @@ class RWKV_x070:
                 lw.pack_for_fused(self.z, i)
                 if ffn_dtype == torch.int8:
                     lw.quantize_ffn(self.z, i)
+                lw.f_V_rows = lw.f_V.contiguous() if self.sparse_bsz1 else None
             torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ reference surface
@@ -401,7 +407,10 @@ class RWKV_x070:
             else:
                 kf = F.linear(kin[0], lw.f_K)
                 ops.relu_sq_(kf)
-                delta = kf @ lw.f_V
+                if rows == 1 and lw.f_V_rows is not None:
+                    delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
+                else:
+                    delta = kf @ lw.f_V
         if T > 1 and not full_output:
             x, delta, rows_out = x[:, -1, :].contiguous(), delta[:, -1, :].contiguous(), (B, 1)
         else:

@@ -159,3 +159,29 @@ def test_mm8_channel_mix_model_vs_oracle(oracle):
         assert rel_linf(st8[1].cpu().numpy(), st_np[1]) <= 2e-3
         q_err = rel_linf(lg8.cpu().numpy(), lg16.cpu().numpy())
         assert 1e-4 < q_err < 0.08, q_err
+
+
+def test_bsz1_sparse_channel_mix_path(oracle):
+    """Config 0 (bsz 1 greedy decode): ffn.value through the sparse vec x mat kernel (rows with a zero
+    relu^2 input are never read, Albatross/rwkv7.py:653-662) gives the reference's ids and the dense
+    path's logits to fp16 noise."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    args = lambda: types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
+    ms = RWKV_x070(args(), state_dict=zd, device="cuda:0", sparse_bsz1=True)
+    md = RWKV_x070(args(), state_dict=zd, device="cuda:0")
+    assert ms.sparse_bsz1 and ms._layers[0].f_V_rows.shape == (512, 128)
+    for row in (0, 1):
+        st_s, st_d = ms.generate_zero_state(0), md.generate_zero_state(0)
+        lg_s = ms.forward(d["greedy:prompt"][row].tolist(), st_s)
+        lg_d = md.forward(d["greedy:prompt"][row].tolist(), st_d)
+        ids = []
+        for _ in range(d["greedy:ids"].shape[1]):
+            assert rel_linf(lg_s.cpu().numpy(), lg_d.cpu().numpy()) <= 2e-3
+            tok = int(lg_s.float().argmax())
+            ids.append(tok)
+            lg_s = ms.forward([tok], st_s)          # bsz-less forward_one -> sparse kernel
+            lg_d = md.forward([tok], st_d)
+        assert ids == d["greedy:ids"][row].tolist()
