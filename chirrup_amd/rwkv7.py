@@ -233,7 +233,9 @@ class RWKV_x070:
     def forward_one(self, x: torch.Tensor, state):
         """bsz-less single token (state tensors without a batch dim), rwkv7.py:287-316."""
         st = [state[0].unsqueeze(2), state[1].unsqueeze(1), state[2].reshape(1)]
-        out = self._forward_embedded(x.reshape(1, 1, -1), st, 1, False)
+        # clone: x may be a VIEW of an embedding row (forward(int)), and the fused path updates the
+        # residual stream in place
+        out = self._forward_embedded(x.reshape(1, 1, -1).clone(), st, 1, False)
         state[2] += 1
         return out.reshape(-1)
 

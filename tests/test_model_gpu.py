@@ -185,3 +185,19 @@ def test_bsz1_sparse_channel_mix_path(oracle):
             lg_s = ms.forward([tok], st_s)          # bsz-less forward_one -> sparse kernel
             lg_d = md.forward([tok], st_d)
         assert ids == d["greedy:ids"][row].tolist()
+
+
+def test_bszless_decode_does_not_corrupt_the_embedding_table():
+    """Regression: forward(int) hands a VIEW of an embedding row to the fused path, which updates the
+    residual stream in place."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    m = RWKV_x070(types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused"), state_dict=zd, device="cuda:0")
+    emb = m.z["emb.weight"].clone()
+    st = m.generate_zero_state(0)
+    for tok in (5, 7, 5, 5, 9):
+        m.forward(tok, st)
+        m.forward([tok], st)
+    assert torch.equal(m.z["emb.weight"], emb)
