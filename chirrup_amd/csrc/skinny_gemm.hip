@@ -276,9 +276,9 @@ int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, i
 #define GO(MTV)                                                                                                              \
     do {                                                                                                                     \
         if (lds > 65536) {                                                                                                   \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>),                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>),                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-            hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_F16>),                        \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_F16>),                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
         }                                                                                                                    \
         if (partial)                                                                                                         \

@@ -70,14 +70,36 @@ __device__ __forceinline__ f16 decay_term(f16 w_raw, float dither) {
     return (f16)((e2 - 1.0f) + dither);
 }
 
+__device__ __forceinline__ f16 hf(float x) { return (f16)x; }          // one rounding to binary16
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float wave_sum(float v) {                  // all 64 lanes get the total
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Extra operands of the fused time-mix form (MODE > 0): the gating chain of rwkv7.py:629-637 in front of
+// the state update and the group-norm / bonus / gate chain of :647-649 behind it run inside this kernel.
+struct TmixArgs {
+    const f16 *a_pre;      // [B,T,C]  a0 + (xa@a1)@a2, before the sigmoid
+    const f16 *vg_pre;     // [B,T,C]  v0 + (xv@v1)@v2, before the sigmoid (layers > 0), else nullptr
+    const f16 *v_first;    // [B,T,C]  layer 0's v (layers > 0), else nullptr
+    const f16 *g;          // [B,T,C]
+    const f16 *k_k, *k_a, *r_k, *lnx_w, *lnx_b;   // [C]
+    float eps;
+};
+
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
+// MODE 0: the operator of the reference (inputs a = -kk, b = kk*a given).  MODE 1: fused time-mix core:
+// k, v are the RAW projections, a_/b_ are unused, y_ receives (group_norm(y) + bonus*v) * g.
+template <int MODE>
 __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const int T, const int C, const int H, f16 *__restrict__ state, const int64_t slot_stride,
     const int32_t *__restrict__ slot_idx, const f16 *__restrict__ r_, const f16 *__restrict__ w_,
     const f16 *__restrict__ k_, const f16 *__restrict__ v_, const f16 *__restrict__ a_,
-    const f16 *__restrict__ b_, f16 *__restrict__ y_, const int32_t *__restrict__ elapsed_t) {
+    const f16 *__restrict__ b_, f16 *__restrict__ y_, const int32_t *__restrict__ elapsed_t, const TmixArgs tm) {
     // [0, 8192): swizzled state image; then r, w~, k, a, b strips of 128 B each.
     __shared__ __attribute__((aligned(16))) unsigned char smem[kStateBytes + 5 * kVecBytes];
 
@@ -97,7 +119,20 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
 
     // ---- first timestep's vectors (lane j holds channel j of the head) ----
     int64_t o = (int64_t)bb * T * C + (int64_t)h * 64 + lane;
-    f16 rj = r_[o], wj = w_[o], kj = k_[o], aj = a_[o], bj = b_[o], vi = v_[o];
+    f16 rj = r_[o], wj = w_[o], kj = k_[o], vi = v_[o];
+    f16 aj, bj, gj = (f16)0.f, vgj = (f16)0.f, vfj = (f16)0.f;     // MODE 1: aj carries a_pre
+    f16 p_kk = (f16)0.f, p_ka = (f16)0.f, p_rk = (f16)0.f, p_lw = (f16)0.f, p_lb = (f16)0.f;
+    if (MODE == 0) {
+        aj = a_[o];
+        bj = b_[o];
+    } else {
+        const int ch = h * 64 + lane;
+        aj = tm.a_pre[o];
+        bj = (f16)0.f;
+        gj = tm.g[o];
+        if (tm.v_first) { vgj = tm.vg_pre[o]; vfj = tm.v_first[o]; }
+        p_kk = tm.k_k[ch]; p_ka = tm.k_a[ch]; p_rk = tm.r_k[ch]; p_lw = tm.lnx_w[ch]; p_lb = tm.lnx_b[ch];
+    }
     const int32_t et = elapsed_t[bb];
 
     // The DMA is older than every load above, and vmcnt retires in order, but make the
@@ -128,16 +163,38 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     for (int t = 0; t < T; t++) {
         // dither: int32 wrap-around multiply, int -> float, exact scale (.cu:23, :59)
         const float dither = kTwoToNeg41 * (float)(int32_t)(kRo1 * (uint32_t)(et + t));
-        vec[0 * 64 + lane] = rj;
+        f16 k_in = kj, a_in = aj, b_in = bj, vv = vi;
+        const f16 r_cur = rj, g_cur = gj;
+        if (MODE == 1) {
+            // rwkv7.py:629-637, one rounding per torch op; the head's L2 norm is a wavefront reduction
+            const float a = (float)hf(sigmoid_f((float)aj));
+            const float kk_in = (float)hf((float)kj * (float)p_kk);
+            float nrm = (float)hf(sqrtf(wave_sum(kk_in * kk_in)));
+            nrm = nrm > 0.f ? nrm : 0.f;                    // clamp_min(1e-12) is 0 in binary16
+            const float kk = (float)hf(kk_in / nrm);
+            k_in = hf((float)kj * (float)hf(1.0f + (float)hf((float)hf(a - 1.0f) * (float)p_ka)));
+            a_in = hf(-kk);
+            b_in = hf(kk * a);
+            if (tm.v_first) {
+                const float gate = (float)hf(sigmoid_f((float)vgj));
+                vv = hf((float)vi + (float)hf((float)hf((float)vfj - (float)vi) * gate));
+            }
+        }
+        vec[0 * 64 + lane] = r_cur;
         vec[1 * 64 + lane] = decay_term(wj, dither);
-        vec[2 * 64 + lane] = kj;
-        vec[3 * 64 + lane] = aj;
-        vec[4 * 64 + lane] = bj;
-        const f16 vv = vi;
+        vec[2 * 64 + lane] = k_in;
+        vec[3 * 64 + lane] = a_in;
+        vec[4 * 64 + lane] = b_in;
         const int64_t o_cur = o;
         if (t + 1 < T) {  // prefetch the next timestep's vectors under this step's arithmetic
             o += C;
-            rj = r_[o]; wj = w_[o]; kj = k_[o]; aj = a_[o]; bj = b_[o]; vi = v_[o];
+            rj = r_[o]; wj = w_[o]; kj = k_[o]; vi = v_[o];
+            if (MODE == 0) {
+                aj = a_[o]; bj = b_[o];
+            } else {
+                aj = tm.a_pre[o]; gj = tm.g[o];
+                if (tm.v_first) { vgj = tm.vg_pre[o]; vfj = tm.v_first[o]; }
+            }
         }
         __builtin_amdgcn_s_barrier();  // single-wave workgroup: orders the LDS strip, never waits
 
@@ -158,7 +215,19 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
             S[p] = s;
             y2 = y2 + s * R2[p];
         }
-        y_[o_cur] = y2.x + y2.y;
+        const f16 yv = y2.x + y2.y;
+        if (MODE == 0) {
+            y_[o_cur] = yv;
+        } else {
+            // rwkv7.py:647-649: group_norm over the head (lane i holds y[i]), + (sum_j r*k*r_k) * v, * g
+            const float yf = (float)yv;
+            const float mean = wave_sum(yf) * (1.0f / 64.0f);
+            const float dlt = yf - mean;
+            const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / 64.0f) + tm.eps);
+            const float gn = (float)hf(dlt * rstd * (float)p_lw + (float)p_lb);
+            const float bonus = (float)hf(wave_sum((float)hf((float)hf((float)r_cur * (float)k_in) * (float)p_rk)));
+            y_[o_cur] = hf((float)hf(gn + (float)hf(bonus * (float)vv)) * (float)g_cur);
+        }
         __builtin_amdgcn_s_barrier();  // strip is rewritten next iteration
     }
 
@@ -206,12 +275,36 @@ extern "C" int WKV7_CAT(wkv7_fwd_seq, WKV7_ENTRY_SUFFIX)(int B, int T, int C, in
     const int rc = check_args(B, T, C, H, state, r, w, k, v, a, b, y, elapsed_t, slot_stride);
     if (rc != CHIRRUP_OK) return rc;
     if (slot_stride == 0) slot_stride = (int64_t)H * 4096;
-    hipLaunchKernelGGL(wkv7_seq_kernel, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
+    hipLaunchKernelGGL(wkv7_seq_kernel<0>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
                        static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
                        static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v),
-                       static_cast<const f16 *>(a), static_cast<const f16 *>(b), static_cast<f16 *>(y), elapsed_t);
+                       static_cast<const f16 *>(a), static_cast<const f16 *>(b), static_cast<f16 *>(y), elapsed_t, TmixArgs{});
     return (int)hipGetLastError();
 }
+
+#ifndef WKV7_VARIANT_BUILD
+// Fused time-mix core: gating (rwkv7.py:629-637) + WKV7 (:645) + group-norm / bonus / gate (:647-649).
+extern "C" int rwkv7_tmix_wkv7_fused(int B, int T, int C, int H, void *state, const void *r, const void *w,
+                                     const void *k, const void *v, const void *a_pre, const void *vg_pre,
+                                     const void *v_first, const void *g, const void *k_k, const void *k_a,
+                                     const void *r_k, const void *lnx_w, const void *lnx_b, float eps, void *out,
+                                     const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride,
+                                     void *stream) {
+    const int rc = check_args(B, T, C, H, state, r, w, k, v, a_pre, g, out, elapsed_t, slot_stride);
+    if (rc != CHIRRUP_OK) return rc;
+    if (!k_k || !k_a || !r_k || !lnx_w || !lnx_b) return CHIRRUP_E_NULL;
+    if ((vg_pre == nullptr) != (v_first == nullptr)) return CHIRRUP_E_NULL;
+    if (slot_stride == 0) slot_stride = (int64_t)H * 4096;
+    TmixArgs tm{static_cast<const f16 *>(a_pre), static_cast<const f16 *>(vg_pre), static_cast<const f16 *>(v_first),
+                static_cast<const f16 *>(g), static_cast<const f16 *>(k_k), static_cast<const f16 *>(k_a),
+                static_cast<const f16 *>(r_k), static_cast<const f16 *>(lnx_w), static_cast<const f16 *>(lnx_b), eps};
+    hipLaunchKernelGGL(wkv7_seq_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
+                       static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
+                       static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v), nullptr, nullptr,
+                       static_cast<f16 *>(out), elapsed_t, tm);
+    return (int)hipGetLastError();
+}
+#endif
 
 #ifndef WKV7_VARIANT_BUILD
 extern "C" int wkv7_fwd_one(int B, int C, int H, void *state, const void *r, const void *w, const void *k,

@@ -203,6 +203,29 @@ def tmix_post(rows: int, C: int, y, r, k, v, g, r_k, lnx_w, lnx_b, eps: float, o
     _lib.check(rc, "rwkv7_tmix_post")
 
 
+def tmix_wkv7_fused(B: int, T: int, C: int, H: int, state, r, w, k, v, a_pre, vg_pre, v_first, g, k_k, k_a, r_k, lnx_w,
+                    lnx_b, eps: float, out, elapsed_t, slot_idx=None) -> None:
+    """Gating + WKV7 + group-norm/bonus/gate in one kernel (include/chirrup_amd.h: rwkv7_tmix_wkv7_fused)."""
+    if H * HEAD_SIZE != C:
+        raise _lib.ChirrupAmdError(f"H*64 != C ({H}*64 != {C})")
+    _chk(state, "state", torch.float16)
+    n_slots = state.numel() // (H * HEAD_SIZE * HEAD_SIZE)
+    for name, t in (("r", r), ("w", w), ("k", k), ("v", v), ("a_pre", a_pre), ("vg_pre", vg_pre), ("v_first", v_first),
+                    ("g", g), ("out", out)):
+        _chk16(name, t, B * T * C)
+    for name, t in (("k_k", k_k), ("k_a", k_a), ("r_k", r_k), ("lnx_w", lnx_w), ("lnx_b", lnx_b)):
+        _chk16(name, t, C)
+    _chk(elapsed_t, "elapsed_t", torch.int32, (B,))
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    elif n_slots != B:
+        raise _lib.ChirrupAmdError(f"state has {n_slots} slots for batch {B} and no slot_idx")
+    rc = _lib.load().rwkv7_tmix_wkv7_fused(B, T, C, H, state.data_ptr(), _ptr(r), _ptr(w), _ptr(k), _ptr(v), _ptr(a_pre),
+                                           _ptr(vg_pre), _ptr(v_first), _ptr(g), _ptr(k_k), _ptr(k_a), _ptr(r_k), _ptr(lnx_w),
+                                           _ptr(lnx_b), eps, _ptr(out), elapsed_t.data_ptr(), _ptr(slot_idx), 0, _stream())
+    _lib.check(rc, "rwkv7_tmix_wkv7_fused")
+
+
 def relu_sq_(x) -> None:
     _chk16("x", x)
     rc = _lib.load().rwkv7_relu_sq(x.numel(), _ptr(x), _stream())

@@ -163,6 +163,7 @@ class RWKV_x070:
         # on a side stream, forked and joined with events (capturable in the decode graph)
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
+        self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -389,13 +390,20 @@ class RWKV_x070:
             r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
             vg_pre = up[0].view(B, T, C) if i > 0 else None
             w, a_pre, g = (up[j - p0].view(B, T, C) for j in (1, 2, 3))
-            ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)
-            if i == 0:
-                v_first = v
             if not s1[i].is_contiguous():
                 raise ops._lib.ChirrupAmdError("state[1][layer] view must be contiguous (slice the batch dim only)")
-            self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
-            ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
+            if self.fuse_tmix_core:
+                # gating + WKV7 + group-norm/bonus/gate in ONE kernel; k', v', -kk, kk*a, y never reach HBM
+                ops.tmix_wkv7_fused(B, T, C, H, s1[i], r, w, k, v, a_pre, vg_pre, v_first if i > 0 else None, g, lw.k_k,
+                                    lw.k_a, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in, elapsed, slot_idx)
+                if i == 0:
+                    v_first = v
+            else:
+                ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)
+                if i == 0:
+                    v_first = v
+                self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
+                ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
             att = F.linear(o_in, lw.O)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]

@@ -128,6 +128,21 @@ int rwkv7_tmix_post(int64_t rows, int C, const void *y, const void *r, const voi
  * a and v unchanged (:629, :637). */
 int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems, void *hbuf, void *stream);
 
+/*
+ * Fused time-mix core (one launch per layer): the gating chain of rwkv7.py:629-637 (as rwkv7_tmix_mid),
+ * the WKV7 update of wkv7_fwd_seq with a = -kk, b = kk*a, and the output chain of :647-649 (as
+ * rwkv7_tmix_post), all inside the WKV7 kernel -- lane j of a head's wavefront holds channel j, the
+ * head reductions (L2 norm, group-norm moments, bonus sum) are wavefront shuffles, and k', v', -kk,
+ * kk*a, y never exist in HBM.  r, w, k, v are the RAW projections ([B][T][C]); out [B][T][C].
+ * vg_pre / v_first both NULL for layer 0.  Same arithmetic (one rounding per torch op) as the three
+ * separate kernels; only the order of the binary32 head reductions differs.
+ */
+int rwkv7_tmix_wkv7_fused(int B, int T, int C, int H, void *state, const void *r, const void *w, const void *k,
+                          const void *v, const void *a_pre, const void *vg_pre, const void *v_first, const void *g,
+                          const void *k_k, const void *k_a, const void *r_k, const void *lnx_w, const void *lnx_b,
+                          float eps, void *out, const int32_t *elapsed_t, const int32_t *slot_idx,
+                          int64_t slot_stride, void *stream);
+
 /* rwkv7.py:678: x <- relu(x)**2 in place over n elements (n % 8 == 0). */
 int rwkv7_relu_sq(int64_t n, void *x, void *stream);
 

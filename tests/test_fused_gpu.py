@@ -130,3 +130,43 @@ def test_relu_sq_exact():
     with np.errstate(over="ignore"):
         want = np.maximum(x, F16(0)) * np.maximum(x, F16(0))
     assert np.array_equal(bits(t.cpu().numpy()), bits(want))
+
+
+@pytest.mark.parametrize("B,T,C,layer0", [(3, 1, 128, True), (4, 3, 256, False), (200, 1, 4096, False)])
+def test_fused_tmix_core_equals_three_kernel_path(oracle, B, T, C, layer0):
+    """rwkv7_tmix_wkv7_fused (gating + WKV7 + group-norm/bonus/gate in one kernel) against tmix_mid ->
+    wkv7_fwd_seq -> tmix_post.  Same per-op roundings; only the order of the binary32 head reductions
+    differs (8-lane partials vs a 64-lane butterfly), so outputs and state may differ by an ulp on a
+    small fraction of elements, never more."""
+    from chirrup_amd import ops
+    from util import wkv7_inputs
+
+    rng = np.random.default_rng(B + T + C)
+    H, rows = C // 64, B * T
+    state, r, w, k, v, _, _, et = wkv7_inputs(B, T, C, seed=B * 3 + C)
+    mk = lambda s=1.0: (rng.standard_normal((B, T, C)) * s).astype(F16)
+    a_pre, vg_pre, v_first, g = mk(), mk(), mk(), mk()
+    k_k = (0.85 + 0.05 * rng.standard_normal(C)).astype(F16)
+    k_a = (1 + 0.05 * rng.standard_normal(C)).astype(F16)
+    r_k = (0.1 * rng.standard_normal(C)).astype(F16)
+    lw = (1 + 0.1 * rng.standard_normal(C)).astype(F16)
+    lb = (0.1 * rng.standard_normal(C)).astype(F16)
+    # three-kernel path
+    tk, tv = cu(k), cu(v)
+    nk, kka = torch.empty_like(tk), torch.empty_like(tk)
+    ops.tmix_mid(rows, C, tk, tv, cu(a_pre), None if layer0 else cu(vg_pre), None if layer0 else cu(v_first), cu(k_k), cu(k_a), nk, kka)
+    S3 = cu(state)
+    y = torch.empty((B, T, C), dtype=torch.float16, device="cuda")
+    ops.forward_seq(B, T, C, H, S3, cu(r), cu(w), tk, tv, nk, kka, y, cu(et))
+    out3 = torch.empty_like(y)
+    ops.tmix_post(rows, C, y, cu(r), tk, tv, cu(g), cu(r_k), cu(lw), cu(lb), 64e-5, out3)
+    # fused
+    S1 = cu(state)
+    out1 = torch.empty((B, T, C), dtype=torch.float16, device="cuda")
+    ops.tmix_wkv7_fused(B, T, C, H, S1, cu(r), cu(w), cu(k), cu(v), cu(a_pre), None if layer0 else cu(vg_pre),
+                        None if layer0 else cu(v_first), cu(g), cu(k_k), cu(k_a), cu(r_k), cu(lw), cu(lb), 64e-5, out1, cu(et))
+    s_a, s_b = S1.cpu().numpy(), S3.cpu().numpy()
+    scale = max(1.0, float(np.abs(s_b.astype(F32)).max()))
+    assert (bits(s_a) != bits(s_b)).mean() < 0.02
+    assert float(np.abs(s_a.astype(F32) - s_b.astype(F32)).max()) <= 2e-3 * scale
+    assert_close_ulps(out1.cpu().numpy(), out3.cpu().numpy(), 2, 0.05, "out", atol=4e-3 * max(1.0, float(out3.abs().max())))
