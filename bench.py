@@ -68,7 +68,7 @@ def make_state(model, B, seed=1234):
     return st
 
 
-def wkv7_event_timing(model, state, B, iters=6):
+def wkv7_event_timing(model, state, B, iters=6, fused=True):
     """Average WKV7 launch duration (ms): HIP events on the launch stream around a HIP-graph replay of
     L back-to-back launches, one per layer state of the model (L*B*H*8 KiB in rotation >> the 256 MiB
     Infinity Cache), real-shaped inputs.  The graph removes host launch gaps, which at small batch
@@ -86,9 +86,16 @@ def wkv7_event_timing(model, state, B, iters=6):
     y = torch.empty((B, 1, C), dtype=torch.float16, device=dev)
     snap = state[1].clone()
 
+    lw = model._layers[min(1, L - 1)]
+    vg, vf, gg = mk(1.0), mk(1.0), mk(1.0)
+
     def run():
         for layer in range(L):
-            ops.forward_seq(B, 1, C, H, state[1][layer], r, w, k, v, a, b, y, state[2])
+            if fused:      # the kernel the decode step really runs: gating + WKV7 + output chain (MODE 1)
+                ops.tmix_wkv7_fused(B, 1, C, H, state[1][layer], r, w, k, v, a, vg, vf, gg, lw.k_k, lw.k_a, lw.r_k,
+                                    lw.lnx_w, lw.lnx_b, 64e-5, y, state[2])
+            else:          # the bare operator of boundary B1
+                ops.forward_seq(B, 1, C, H, state[1][layer], r, w, k, v, a, b, y, state[2])
 
     run()
     torch.cuda.synchronize()
@@ -108,13 +115,15 @@ def wkv7_event_timing(model, state, B, iters=6):
     return ms[len(ms) // 2]
 
 
-def recorded_traffic(B, C):
+def recorded_traffic(B, C, fused=False):
     """HBM bytes per WKV7 launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, gfx950 correction applied) -- only when they were taken at this shape."""
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*wkv7_pmc_traffic.json")), reverse=True):
         rec = json.load(open(f))
+        if ("<1>" in rec["kernel"]) != fused:
+            continue
         if rec["shape"]["B"] == B and rec["shape"]["C"] == C:
             return rec["traffic_bytes_per_launch"], os.path.basename(f)
     return None, None
@@ -221,18 +230,24 @@ def main():
         timed_step()
     dt = timed_region(timed_step, a.steps, dev)       # barrier + sync on both sides, max over ranks
 
-    wkv_ms = wkv7_event_timing(model, state, B)
+    fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
+    wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
+    wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * B * a.steps / dt
-        bytes_per_launch = B * (270 * C + 4)
+        # algorithmic bytes per (slot, layer, token): state read+write 256*C, elapsed_t 4, plus the per-token
+        # vectors: operator form 6 in + 1 out = 14*C (270*C+4); fused time-mix core 8 in + 1 out = 18*C
+        op_bytes = B * (270 * C + 4)
+        bytes_per_launch = B * (274 * C + 4) if fused_core else op_bytes
         achieved = bytes_per_launch / (wkv_ms * 1e-3) / 1e9
-        traffic, traffic_src = recorded_traffic(B, C)
+        traffic, traffic_src = recorded_traffic(B, C, fused_core)
+        op_traffic, _ = recorded_traffic(B, C, False)
         weight_bytes = 0
         for n, t in model.z.items():
             if n != "emb.weight":
                 weight_bytes += sum(x.numel() * x.element_size() for x in (t if isinstance(t, tuple) else (t,)))
-        step_bytes = weight_bytes + L * bytes_per_launch + B * 65536 * 2
+        step_bytes = weight_bytes + L * op_bytes + B * 65536 * 2
         out = {
             "metric": "decode tokens/sec (whole job) and tps/request, RWKV7-g1 " + a.model + f" bsz={B}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -243,10 +258,13 @@ def main():
                                    "greedy decode step incl. sampling and token-id D2H; random-init weights",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "graph": not a.no_graph, "fused_elementwise": not a.no_fused},
-            "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel<1> (fused time-mix core)" if fused_core else "wkv7_seq_kernel<0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "launch_us": round(wkv_ms * 1e3, 2),
-                         "launches_per_step": L},
+                         "launches_per_step": L,
+                         "wkv7_operator_only": {"bytes_per_launch": op_bytes, "launch_us": round(wkv_op_ms * 1e3, 2),
+                                                "achieved": round(op_bytes / (wkv_op_ms * 1e-3) / 1e9, 1),
+                                                "frac": round(op_bytes / (wkv_op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": op_traffic}},
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
