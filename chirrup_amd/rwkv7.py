@@ -507,6 +507,49 @@ class DecodeGraph:
         return self.logits
 
 
+class SlotDecodeGraph:
+    """HIP-graph replay of ONE decode step over a slot pool (``forward_slots`` with T = 1) at a fixed
+    batch shape.  Rows beyond the live count point at a PARKING slot the caller never hands to a
+    request (its contents are garbage by design), so one captured graph serves any number of live rows
+    up to ``B``; the worker keeps a few bucket sizes.  Inputs are written into static buffers."""
+
+    def __init__(self, model: RWKV_x070, pool, B: int, parking_slot: int, warmup: int = 2):
+        assert model.fused, "needs the HIP path"
+        self.model, self.pool, self.B, self.parking = model, pool, B, parking_slot
+        dev = model.device
+        self.tokens = torch.zeros((B, 1), dtype=torch.long, device=dev)
+        self.slot_idx = torch.full((B,), parking_slot, dtype=torch.int32, device=dev)
+        snap = [t.clone() for t in pool]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                model.forward_slots(self.tokens, pool, self.slot_idx)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.logits = model.forward_slots(self.tokens, pool, self.slot_idx)
+        torch.cuda.synchronize()
+        for t, s_ in zip(pool, snap):
+            t.copy_(s_)
+        self._tok_host = torch.zeros((B, 1), dtype=torch.long).pin_memory()
+        self._idx_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+
+    def run(self, tokens: Sequence[int], slots: Sequence[int]) -> torch.Tensor:
+        """tokens[i] goes to slot slots[i]; returns the static logits tensor, rows [0, len(slots)) valid."""
+        n = len(slots)
+        assert n <= self.B and len(tokens) == n
+        self._tok_host.zero_()
+        self._idx_host.fill_(self.parking)
+        self._tok_host[:n, 0] = torch.as_tensor(tokens, dtype=torch.long)
+        self._idx_host[:n] = torch.as_tensor(slots, dtype=torch.int32)
+        self.tokens.copy_(self._tok_host, non_blocking=True)
+        self.slot_idx.copy_(self._idx_host, non_blocking=True)
+        self.graph.replay()
+        return self.logits
+
+
 def model_args(model_path: str, vocab_size: int = 65536, head_size: int = 64):
     """The namespace the worker builds (chirrup/worker.py:212-218)."""
     a = types.SimpleNamespace()

@@ -98,7 +98,8 @@ class Worker:
 
         if self.model is None:
             self.model = RWKV_x070(model_args(self.model_config.model_path, self.model_config.vocab_size,
-                                              self.model_config.head_size))
+                                              self.model_config.head_size),
+                                   ffn_dtype=torch.int8 if self.model_config.dtype == torch.int8 else torch.float16)
         if self.tokenizer is None:
             self.tokenizer = TRIE_TOKENIZER(self.model_config.vocab_path)
         self._post({"status": "success", "worker_id": self.worker_id, "gpu_id": self.gpu_id,
@@ -129,6 +130,9 @@ class Worker:
         self.penalty_decay_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
         self.presence_penalty_tensor = torch.zeros((n, 1), **f32)
         self._greedy = [True] * n
+        # decode-step HIP graphs per batch bucket (captured lazily); slot n-1 is the parking slot
+        self._graphs = {}
+        self.use_graph = bool(getattr(self.model, "fused", False)) and self.device.type == "cuda"
 
     # ------------------------------------------------------------------ per-slot bookkeeping (host only)
     def _process_events(self) -> bool:
@@ -277,9 +281,12 @@ class Worker:
         slots = decode_slots + prefill_slots
         if not slots:
             return
-        tokens = [[self.state_slot[s]["next_input_token"]] for s in slots]
         idx = self._slot_tensor(slots)
-        out = self.model.forward_slots(tokens, self.batch_state, idx)
+        if self.use_graph:
+            out = self._graph_for(len(slots)).run([self.state_slot[s]["next_input_token"] for s in slots], slots)
+        else:
+            tokens = [[self.state_slot[s]["next_input_token"]] for s in slots]
+            out = self.model.forward_slots(tokens, self.batch_state, idx)
         nd = len(decode_slots)
         if nd == 0:
             return
@@ -303,6 +310,19 @@ class Worker:
         host_ids = ids.tolist()                  # ONE device->host copy for the whole batch
         for j, s in enumerate(decode_slots):
             self.state_slot[s]["new_token"] = int(host_ids[j])
+
+    def _graph_for(self, n: int):
+        """Smallest captured bucket >= n (buckets: powers of two up to the slot count)."""
+        from .rwkv7 import SlotDecodeGraph
+
+        b = 1
+        while b < n:
+            b *= 2
+        b = min(b, self.max_batch_size)
+        g = self._graphs.get(b)
+        if g is None:
+            g = self._graphs[b] = SlotDecodeGraph(self.model, self.batch_state, b, parking_slot=self.real_state_size - 1)
+        return g
 
     def _run_forward_seq(self, seq_slots: List[int]):
         lens = [len(self.state_slot[s]["task"].prefill_tokens) - max(self.state_slot[s]["task"].cache_prefill_padding - 1, 0)
