@@ -29,7 +29,8 @@ def timed_region(fn: Callable[[], None], steps: int, device: torch.device) -> fl
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if device.type == "cuda" else "cpu")
+        on_gpu = device.type == "cuda" and dist.get_backend() == "nccl"
+        t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
