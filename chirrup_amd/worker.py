@@ -19,7 +19,8 @@ What is different is the DEVICE DISPATCH, redesigned for a 288 GB MI355X:
   * penalties + greedy sampling of all decode rows are one kernel and one D2H copy of B ids
     (ops.penalize_argmax) instead of ~8 torch kernels and B ``.item()`` syncs (:719-740); rows with
     real sampling parameters go through samplers.sample_logits_rwkv_pip_compatible.
-  * prefix states exported for the cache are gathered on the device and copied out once.
+  * prefix states exported for the cache stay in HBM by default (device clones; `state_cache_device="cpu"`
+    restores the reference's host copies) -- a cache hit is then a 17-33 MB device-to-device copy.
 """
 import queue
 import time
@@ -72,7 +73,7 @@ def _empty_slot() -> dict:
 class Worker:
     def __init__(self, worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, task_queue: queue.Queue,
                  master_event_queue: queue.Queue, worker_event_queue: Optional[queue.Queue], batch_size: int = 32,
-                 model=None, tokenizer=None, penalize_argmax=None):
+                 model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None):
         self.worker_id, self.gpu_id, self.model_config = worker_id, gpu_id, model_config
         self.task_queue, self.master_event_queue, self.worker_event_queue = task_queue, master_event_queue, worker_event_queue
         self.real_state_size = batch_size
@@ -82,6 +83,10 @@ class Worker:
         self.model, self.tokenizer = model, tokenizer   # may be injected (tests use a fake backend)
         self._penalize_argmax = penalize_argmax if penalize_argmax is not None else ops.penalize_argmax
         self.batch_state = None
+        # where exported prefix states live: None = the pool's own device (HBM-resident prefix cache:
+        # 17-33 MB device-to-device copies instead of two PCIe transfers per cache hit); "cpu" = the
+        # reference's behaviour (worker.py:427-429)
+        self.state_cache_device = state_cache_device
         self.no_penalty_token_ids = {33, 10, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58}
         self.min_forward_seq_len = 10
         self.max_forward_seq_len_per_forward = 100
@@ -156,8 +161,10 @@ class Worker:
     def _export_state(self, slot: int):
         """[state0[:, :, [s]], state1[:, [s]], state2[[s]]] on the CPU (worker.py:426-430)."""
         s0, s1, s2 = self.batch_state
-        return [s0[:, :, [slot], :].to("cpu", non_blocking=True), s1[:, [slot], :, :].to("cpu", non_blocking=True),
-                s2[[slot]].to("cpu", non_blocking=True)]
+        parts = [s0[:, :, [slot], :], s1[:, [slot], :, :], s2[[slot]]]      # advanced indexing: fresh copies
+        if self.state_cache_device is None:
+            return parts
+        return [p.to(self.state_cache_device, non_blocking=True) for p in parts]
 
     def _maybe_cache_prefill(self, td, slot: int):
         t: Task = td["task"]
