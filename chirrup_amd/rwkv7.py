@@ -353,7 +353,9 @@ class RWKV_x070:
         H, rows, dev = self.n_head, B * T, x.device
         x = x.contiguous()
         new = lambda *shape: torch.empty(shape, dtype=DTYPE, device=dev)
-        mixed, kin, y, o_in, neg_kk, kka = new(6, B, T, C), new(1, B, T, C), new(B, T, C), new(B, T, C), new(B, T, C), new(B, T, C)
+        mixed, kin, o_in = new(6, B, T, C), new(1, B, T, C), new(B, T, C)
+        if not self.fuse_tmix_core:
+            y, neg_kk, kka = new(B, T, C), new(B, T, C), new(B, T, C)
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
 
