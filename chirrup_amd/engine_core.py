@@ -1,0 +1,170 @@
+"""Async engine façade over N single-GPU workers (boundary B4 of SURVEY.md section 8b).
+
+API of the reference's chirrup/engine_core.py: ``AsyncEngineCore().init(worker_num, model_config,
+batch_size)`` -> asyncio.Task that completes when every worker has loaded; ``.completion(prompt_str,
+...)`` -> AsyncEngineCompletion; ``.shutdown()``; ``.iter_worker_performance()``.  One shared host
+task queue, workers pull from it (replica data parallelism, worker k on GPU k); worker -> asyncio
+traffic goes through ``call_soon_threadsafe`` (ThreadSafeAsyncQueue, reference :30-57).
+
+Workers run as daemon threads like in the reference.  On a GIL build the per-iteration host work of
+8 workers serialises (~0.8 ms each per ~10 ms step here); the bench (one process per GPU) does not
+have that limit, and ``worker_factory`` lets a deployment substitute process-backed workers.
+"""
+import asyncio
+import queue
+import threading
+import uuid
+from typing import Any, AsyncIterator, Callable, Dict, List, Optional
+
+from .core_structure import DEFAULT_SAMPLING_CONFIG, DEFAULT_STOP_TOKENS, ModelLoadConfig, Task
+from .interface import AsyncEngineCompletion
+
+
+class ThreadSafeAsyncQueue:
+    """asyncio.Queue that worker threads may put into."""
+
+    def __init__(self, event_loop: asyncio.AbstractEventLoop, q: Optional[asyncio.Queue] = None):
+        self.event_loop = event_loop
+        self.queue: asyncio.Queue = q if q is not None else asyncio.Queue()
+
+    def put_nowait(self, item):
+        if self.event_loop.is_closed():
+            return
+
+        def _put(x):
+            try:
+                self.queue.put_nowait(x)
+            except asyncio.QueueFull:
+                pass                      # bounded queues carry droppable telemetry only
+
+        try:
+            self.event_loop.call_soon_threadsafe(_put, item)
+        except RuntimeError:
+            pass                          # loop already closed
+
+    def empty(self) -> bool:
+        return self.queue.empty()
+
+    def get_nowait(self):
+        return self.queue.get_nowait()
+
+
+class AsyncEngineCore:
+    LOAD_TIMEOUT_S = 300
+
+    def __init__(self, worker_factory: Optional[Callable[..., Any]] = None, tokenizer=None):
+        self.workers: List[Any] = []
+        self.worker_threads: List[threading.Thread] = []
+        self.task_queue: "queue.Queue[Task]" = queue.Queue()
+        self.event_queue: "queue.Queue[Dict[str, Any]]" = queue.Queue()
+        self.worker_id_set = set()
+        self.worker_event_queue: Optional[ThreadSafeAsyncQueue] = None
+        self.event_loop: Optional[asyncio.AbstractEventLoop] = None
+        self.is_initialized = False
+        self.is_shutdown = False
+        self.tokenizer = tokenizer
+        self._worker_factory = worker_factory
+
+    def _make_worker(self, **kw):
+        if self._worker_factory is not None:
+            return self._worker_factory(**kw)
+        from .worker import Worker
+
+        return Worker(**kw)
+
+    def init(self, worker_num: int, model_config: ModelLoadConfig, batch_size: int = 32) -> "asyncio.Task":
+        if self.is_initialized:
+            raise RuntimeError("Workers already initialized")
+        if self.is_shutdown:
+            raise RuntimeError("Engine has been shutdown")
+        try:
+            self.event_loop = asyncio.get_running_loop()
+        except RuntimeError:
+            self.event_loop = asyncio.new_event_loop()
+            asyncio.set_event_loop(self.event_loop)
+        self.worker_event_queue = ThreadSafeAsyncQueue(self.event_loop, asyncio.Queue(maxsize=worker_num * 100))
+        self.is_initialized = True
+        if self.tokenizer is None:
+            from .tokenizer import TRIE_TOKENIZER
+
+            self.tokenizer = TRIE_TOKENIZER(model_config.vocab_path)
+
+        async def wait_loaded():
+            self.worker_id_set = {f"worker_{i}" for i in range(worker_num)}
+            for k, wid in enumerate(sorted(self.worker_id_set)):
+                w = self._make_worker(worker_id=wid, gpu_id=[k], model_config=model_config, task_queue=self.task_queue,
+                                      master_event_queue=self.event_queue, worker_event_queue=self.worker_event_queue,
+                                      batch_size=batch_size)
+                self.workers.append(w)
+                t = threading.Thread(target=w.start, daemon=True, name=f"chirrup:{wid}")
+                t.start()
+                self.worker_threads.append(t)
+            loaded, budget = set(), self.LOAD_TIMEOUT_S
+            while len(loaded) < worker_num and budget > 0:
+                try:
+                    wid, kind, payload = await asyncio.wait_for(self.worker_event_queue.queue.get(), timeout=1.0)
+                except asyncio.TimeoutError:
+                    budget -= 1
+                    continue
+                if kind == "worker_loaded":
+                    if payload.get("status") != "success":
+                        raise RuntimeError(f"Worker {wid} failed to load: {payload}")
+                    loaded.add(wid)
+            if len(loaded) < worker_num:
+                raise RuntimeError(f"workers timed out while loading: {self.worker_id_set - loaded}")
+
+        return asyncio.create_task(wait_loaded())
+
+    def completion(self, prompt_str: str, prefill_tokens: Optional[List[int]] = None, state=None, priority: int = 0,
+                   temperature: float = DEFAULT_SAMPLING_CONFIG["temperature"], top_p: float = DEFAULT_SAMPLING_CONFIG["top_p"],
+                   top_k: int = DEFAULT_SAMPLING_CONFIG["top_k"],
+                   presence_penalty: float = DEFAULT_SAMPLING_CONFIG["presence_penalty"],
+                   frequency_penalty: float = DEFAULT_SAMPLING_CONFIG["frequency_penalty"],
+                   penalty_decay: float = DEFAULT_SAMPLING_CONFIG["penalty_decay"],
+                   stop_tokens: Optional[List[int]] = DEFAULT_STOP_TOKENS, forbidden_tokens: Optional[List[int]] = None,
+                   max_tokens: Optional[int] = DEFAULT_SAMPLING_CONFIG["max_tokens"], task_id: Optional[str] = None,
+                   cache_prefill: bool = False, cache_prefill_padding: int = 0,
+                   return_logits: bool = False) -> AsyncEngineCompletion:
+        assert not (state is not None and prefill_tokens is None), "prefill_tokens cannot be None when state is not None"
+        if not self.is_initialized:
+            raise RuntimeError("Engine not initialized")
+        if self.is_shutdown:
+            raise RuntimeError("Engine has been shutdown")
+        if not prefill_tokens:
+            prefill_tokens = self.tokenizer.encode(prompt_str)
+        return AsyncEngineCompletion(prompt_str=prompt_str, prefill_tokens=list(prefill_tokens), state=state,
+                                     task_queue=self.task_queue, result_channel=ThreadSafeAsyncQueue(self.event_loop),
+                                     task_id=task_id or str(uuid.uuid4()), priority=priority, temperature=temperature,
+                                     top_p=top_p, top_k=top_k, presence_penalty=presence_penalty,
+                                     frequency_penalty=frequency_penalty, penalty_decay=penalty_decay,
+                                     stop_tokens=stop_tokens, forbidden_tokens=forbidden_tokens, max_tokens=max_tokens,
+                                     cache_prefill=cache_prefill, cache_prefill_padding=cache_prefill_padding,
+                                     return_logits=return_logits)
+
+    def shutdown(self) -> None:
+        if self.is_shutdown:
+            return
+        self.is_shutdown = True
+        for _ in range(max(1, len(self.workers))):       # every worker consumes one shutdown event
+            self.event_queue.put_nowait({"type": "shutdown"})
+        for t in self.worker_threads:
+            if t.is_alive():
+                t.join(timeout=5)
+
+    async def iter_worker_performance(self, timeout: float = 1.0) -> AsyncIterator[Dict[str, Any]]:
+        if self.worker_event_queue is None:
+            raise RuntimeError("Engine not initialized")
+        while not self.is_shutdown:
+            try:
+                wid, kind, payload = await asyncio.wait_for(self.worker_event_queue.queue.get(), timeout=timeout)
+            except asyncio.TimeoutError:
+                continue
+            if kind == "worker_performance":
+                yield dict(worker_id=wid, **{k: payload[k] for k in ("avg_loop_time", "state_size", "state_offset_details",
+                                                                       "task_details", "max_allocated_memory_GB")})
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass
