@@ -107,3 +107,217 @@ extern "C" int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurren
                        static_cast<const f16 *>(frequency_penalty), slot_idx, ids, pen);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sort-free top-p / top-k / temperature sampling for the rows that are NOT greedy.
+//
+// Semantics of sample_logits_rwkv_pip_compatible (chirrup/utils/samplers.py:171-255): probs =
+// softmax(logits); cutoff = the probability at which the DESCENDING cumulative sum first reaches top_p,
+// everything below it is dropped (ties at the cutoff stay); optional top-k; probs ** (1/T); one draw
+// from the remaining mass.  The reference sorts all V probabilities per row; here the row's binary16
+// logits sit in LDS (V <= 65536 -> 128 KiB) and the cutoff is found by a two-level radix search over
+// the 16-bit order-preserving keys of the logits (probability is monotone in the logit), 256 bins of
+// probability mass (and of counts, for top-k) per level.  The draw is an inverse-CDF walk in token
+// order with a caller-supplied uniform number per row (torch's generator stays the source of
+// randomness).  Differences from the reference: ties AT the top-k boundary are all kept, and the
+// draw uses one uniform instead of torch.multinomial's stream -- same distribution, different ids.
+namespace {
+
+constexpr int kSampThreads = 1024;
+constexpr int kHistReplicas = 8;
+
+__device__ __forceinline__ unsigned key_of(f16 v) {        // larger value <=> larger key
+    const unsigned short b = __builtin_bit_cast(unsigned short, v);
+    return (b & 0x8000u) ? (unsigned)(unsigned short)~b : (unsigned)(b | 0x8000u);
+}
+
+__device__ __forceinline__ float block_reduce_sum(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < kSampThreads / 64; i++) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float block_reduce_max(float v, float *red) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int i = 0; i < kSampThreads / 64; i++) t = fmaxf(t, red[i]);
+    return t;
+}
+
+__global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
+    const int V, const f16 *__restrict__ logits, const int32_t *__restrict__ rows, const f16 *__restrict__ temperature,
+    const f16 *__restrict__ top_p, const int32_t *__restrict__ top_k, const int32_t *__restrict__ slot_idx,
+    const float *__restrict__ uniform, int32_t *__restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f16 *row = reinterpret_cast<f16 *>(smem);                                   // V halves (padded to 8)
+    float *hmass = reinterpret_cast<float *>(smem + ((size_t)V * 2 + 15) / 16 * 16);   // [replicas][256]
+    unsigned *hcnt = reinterpret_cast<unsigned *>(hmass + kHistReplicas * 256);  // [replicas][256]
+    float *red = reinterpret_cast<float *>(hcnt + kHistReplicas * 256);          // [16]
+    float *scal = red + 16;                                                      // small broadcast area
+    const int tid = threadIdx.x;
+    const int r = rows[blockIdx.x];
+    const int slot = slot_idx ? slot_idx[r] : r;
+    const float T = (float)temperature[slot];
+    const float P = (float)top_p[slot];
+    const int Kk = top_k[slot];
+    const f16 *src = logits + (int64_t)r * V;
+
+    // ---- row -> LDS, max
+    float mx = -INFINITY;
+    for (int c = tid * 8; c < V; c += kSampThreads * 8) {
+        const f16x8 v = *reinterpret_cast<const f16x8 *>(src + c);
+        *reinterpret_cast<f16x8 *>(row + c) = v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) mx = fmaxf(mx, (float)v[e]);
+    }
+    mx = block_reduce_max(mx, red);
+    float z = 0.f;
+    for (int c = tid; c < V; c += kSampThreads) z += __expf((float)row[c] - mx);
+    const float Z0 = block_reduce_sum(z, red);
+    const float target = P * Z0;                 // in un-normalised mass
+
+    // ---- two-level radix search: largest key c_key with mass{key >= c_key} >= target,
+    //      and (top-k) largest key k_key with count{key >= k_key} >= K
+    unsigned prefix = 0;            // high byte once level 0 is done
+    unsigned c_key = 0, k_key = 0;
+    float mass_above = 0.f;         // mass strictly above the current search window
+    unsigned cnt_above = 0;
+    bool p_done = false, k_done = (Kk <= 0);
+    unsigned p_hi = 0, k_hi = 0;
+    float p_mass_above = 0.f;
+    unsigned k_cnt_above = 0;
+    for (int level = 0; level < 2; level++) {
+        // level 1 may need two different high bytes (one for top-p, one for top-k): run it per criterion
+        for (int crit = 0; crit < (level == 0 ? 1 : 2); crit++) {
+            if (level == 1) {
+                if (crit == 0 && p_done) continue;
+                if (crit == 1 && k_done) continue;
+                prefix = crit == 0 ? p_hi : k_hi;
+                mass_above = p_mass_above;
+                cnt_above = k_cnt_above;
+            }
+            for (int i = tid; i < kHistReplicas * 256; i += kSampThreads) { hmass[i] = 0.f; hcnt[i] = 0u; }
+            __syncthreads();
+            const int rep = (tid >> 6) & (kHistReplicas - 1);
+            for (int c = tid; c < V; c += kSampThreads) {
+                const unsigned k16 = key_of(row[c]);
+                if (level == 1 && (k16 >> 8) != prefix) continue;
+                const unsigned bin = level == 0 ? (k16 >> 8) : (k16 & 255u);
+                atomicAdd(&hmass[rep * 256 + bin], __expf((float)row[c] - mx));
+                atomicAdd(&hcnt[rep * 256 + bin], 1u);
+            }
+            __syncthreads();
+            if (tid < 256) {
+                float m = 0.f; unsigned n = 0;
+                for (int q = 0; q < kHistReplicas; q++) { m += hmass[q * 256 + tid]; n += hcnt[q * 256 + tid]; }
+                hmass[tid] = m; hcnt[tid] = n;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                // walk from the largest bin down
+                if (level == 0 || crit == 0) {
+                    if (!p_done) {
+                        float acc = mass_above; int b = 255; bool hit = false;
+                        for (; b >= 0; b--) { if (acc + hmass[b] >= target && hcnt[b] > 0) { hit = true; break; } acc += hmass[b]; }
+                        scal[0] = hit ? (float)b : -1.f; scal[1] = acc;
+                    }
+                }
+                if (level == 0 || crit == 1) {
+                    if (!k_done) {
+                        unsigned acc = cnt_above; int b = 255; bool hit = false;
+                        for (; b >= 0; b--) { if (acc + hcnt[b] >= (unsigned)Kk && hcnt[b] > 0) { hit = true; break; } acc += hcnt[b]; }
+                        scal[2] = hit ? (float)b : -1.f; scal[3] = (float)acc;
+                    }
+                }
+            }
+            __syncthreads();
+            if (level == 0) {
+                if (!p_done) { if (scal[0] < 0.f) { c_key = 0; p_done = true; } else { p_hi = (unsigned)scal[0]; p_mass_above = scal[1]; } }
+                if (!k_done) { if (scal[2] < 0.f) { k_key = 0; k_done = true; } else { k_hi = (unsigned)scal[2]; k_cnt_above = (unsigned)scal[3]; } }
+            } else if (crit == 0) {
+                c_key = scal[0] < 0.f ? (p_hi << 8) : ((p_hi << 8) | (unsigned)scal[0]);
+            } else {
+                k_key = scal[2] < 0.f ? (k_hi << 8) : ((k_hi << 8) | (unsigned)scal[2]);
+            }
+            __syncthreads();
+        }
+    }
+    const unsigned thr = (Kk > 0 && k_key > c_key) ? k_key : c_key;
+
+    // ---- kept mass after temperature, then inverse-CDF draw in token order
+    const float invT = 1.0f / T;
+    const bool hot = T != 1.0f;
+    const int per = (V + kSampThreads - 1) / kSampThreads;       // contiguous chunk per thread
+    const int c0 = tid * per, c1 = (c0 + per) < V ? (c0 + per) : V;
+    float local = 0.f;
+    for (int c = c0; c < c1; c++) {
+        if (key_of(row[c]) >= thr) {
+            float p = __expf((float)row[c] - mx) / Z0;
+            local += hot ? powf(p, invT) : p;
+        }
+    }
+    // exclusive scan of `local` over the 1024 threads
+    float incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o, 64);
+        if ((tid & 63) >= o) incl += t;
+    }
+    __syncthreads();
+    if ((tid & 63) == 63) red[tid >> 6] = incl;
+    __syncthreads();
+    float wave_base = 0.f, total = 0.f;
+    for (int i = 0; i < kSampThreads / 64; i++) { if (i < (tid >> 6)) wave_base += red[i]; total += red[i]; }
+    const float before = wave_base + incl - local;
+    const float want = uniform[blockIdx.x] * total;
+    if (tid == 0) scal[4] = -1.f;
+    __syncthreads();
+    if (local > 0.f && want >= before && want < before + local) {
+        float acc = before; int pick = -1;
+        for (int c = c0; c < c1; c++) {
+            if (key_of(row[c]) >= thr) {
+                float p = __expf((float)row[c] - mx) / Z0;
+                acc += hot ? powf(p, invT) : p;
+                pick = c;
+                if (acc > want) break;
+            }
+        }
+        scal[4] = (float)pick;           // exactly one thread's interval contains `want`
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int pick = (int)scal[4];
+        if (pick < 0) {                  // want == total (u -> 1) or rounding: take the last kept token
+            for (int c = V - 1; c >= 0; c--) if (key_of(row[c]) >= thr) { pick = c; break; }
+        }
+        ids[r] = pick;
+    }
+}
+
+}  // namespace
+
+extern "C" int rwkv7_sample_topp(int n_rows, int V, const void *logits, const int32_t *rows, const void *temperature,
+                                 const void *top_p, const int32_t *top_k, const int32_t *slot_idx, const float *uniform,
+                                 int32_t *ids, void *stream) {
+    if (n_rows <= 0 || V <= 0 || (V & 7) || V > 65536) return CHIRRUP_E_SHAPE;
+    if (!logits || !rows || !temperature || !top_p || !top_k || !uniform || !ids) return CHIRRUP_E_NULL;
+    if (reinterpret_cast<uintptr_t>(logits) & 15) return CHIRRUP_E_ALIGN;
+    const size_t lds = ((size_t)V * 2 + 15) / 16 * 16 + (size_t)kHistReplicas * 256 * 8 + 16 * 4 + 8 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sample_topp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sample_topp_kernel, dim3((unsigned)n_rows), dim3(kSampThreads), lds, static_cast<hipStream_t>(stream), V,
+                       static_cast<const f16 *>(logits), rows, static_cast<const f16 *>(temperature),
+                       static_cast<const f16 *>(top_p), top_k, slot_idx, uniform, ids);
+    return (int)hipGetLastError();
+}

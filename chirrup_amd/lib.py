@@ -36,6 +36,7 @@ SIGNATURES = {
     "rwkv7_tmix_wkv7_fused": (_i, [_i, _i, _i, _i] + [_vp] * 14 + [ctypes.c_float, _vp, _vp, _vp, _i64, _vp]),
     "rwkv7_lora_act": (_i, [_i, _i, _i64, _vp, _vp]),
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
+    "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),

@@ -304,6 +304,29 @@ def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None):
     return out
 
 
+def sample_topp(logits, rows, temperature, top_p, top_k, uniform, ids, slot_idx=None) -> None:
+    """Sort-free top-p/top-k/temperature draw for the listed rows (include/chirrup_amd.h:
+    rwkv7_sample_topp).  logits fp16 [B,V]; rows int32 [n]; temperature/top_p fp16 and top_k int32 per
+    slot; uniform fp32 [n] in [0,1); ids int32 [B] (entries rows[i] are written)."""
+    if not logits.is_cuda or logits.dtype != torch.float16 or logits.dim() != 2 or not logits.is_contiguous():
+        raise _lib.ChirrupAmdError("logits: expected contiguous GPU fp16 [B,V]")
+    B, V = logits.shape
+    n = rows.numel()
+    _chk(rows, "rows", torch.int32, (n,))
+    _chk(uniform, "uniform", torch.float32, (n,))
+    _chk(ids, "ids", torch.int32, (B,))
+    for name, t, dt in (("temperature", temperature, torch.float16), ("top_p", top_p, torch.float16), ("top_k", top_k, torch.int32)):
+        if not t.is_cuda or t.dtype != dt or not t.is_contiguous():
+            raise _lib.ChirrupAmdError(f"{name}: expected contiguous GPU {dt}")
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    elif temperature.numel() < B:
+        raise _lib.ChirrupAmdError("parameter tables shorter than the batch and no slot_idx")
+    rc = _lib.load().rwkv7_sample_topp(n, V, _ptr(logits), _ptr(rows), _ptr(temperature), _ptr(top_p), _ptr(top_k),
+                                       _ptr(slot_idx), _ptr(uniform), _ptr(ids), _stream())
+    _lib.check(rc, "rwkv7_sample_topp")
+
+
 def lora_act_(hbuf, first_plane: int) -> None:
     """hbuf [n, rows, D] fp16, planes first_plane.. of [v, w, a, g]: tanh on w, sigmoid on g."""
     _chk16("hbuf", hbuf)

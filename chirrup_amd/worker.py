@@ -82,6 +82,7 @@ class Worker:
         self.state_slot: Dict[int, dict] = {i: _empty_slot() for i in range(self.max_batch_size)}
         self.model, self.tokenizer = model, tokenizer   # may be injected (tests use a fake backend)
         self._penalize_argmax = penalize_argmax if penalize_argmax is not None else ops.penalize_argmax
+        self._sample_topp = ops.sample_topp if penalize_argmax is None else None     # fake backends use the torch sampler
         self.batch_state = None
         # where exported prefix states live: None = the pool's own device (HBM-resident prefix cache:
         # 17-33 MB device-to-device copies instead of two PCIe transfers per cache hit); "cpu" = the
@@ -310,10 +311,17 @@ class Worker:
                                   self.frequency_penalty_tensor.view(-1), didx)
         sampled = [j for j, s in enumerate(decode_slots) if not self._greedy[s]]
         if sampled:
-            rows = torch.tensor(sampled, device=self.device, dtype=torch.long)
-            srows = didx.long()[rows]
-            ids[rows] = sample_logits_rwkv_pip_compatible(logits[rows], self.temperature_tensor[srows],
-                                                          self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
+            if self._sample_topp is not None and logits.shape[1] <= 65536:
+                # sort-free top-p / top-k / temperature kernel, one workgroup per sampled row
+                rows = torch.tensor(sampled, device=self.device, dtype=torch.int32)
+                u = torch.rand((len(sampled),), device=self.device, dtype=torch.float32)
+                self._sample_topp(logits, rows, self.temperature_tensor.view(-1), self.top_p_tensor.view(-1),
+                                  self.top_k_tensor.view(-1), u, ids, didx)
+            else:
+                rows = torch.tensor(sampled, device=self.device, dtype=torch.long)
+                srows = didx.long()[rows]
+                ids[rows] = sample_logits_rwkv_pip_compatible(logits[rows], self.temperature_tensor[srows],
+                                                              self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
         host_ids = ids.tolist()                  # ONE device->host copy for the whole batch
         for j, s in enumerate(decode_slots):
             self.state_slot[s]["new_token"] = int(host_ids[j])

@@ -186,6 +186,19 @@ int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const f
                           const void *penalty_decay, const void *frequency_penalty, const int32_t *slot_idx,
                           int32_t *ids, void *stream);
 
+/*
+ * Sort-free top-p / top-k / temperature sampling of n_rows rows of `logits` (binary16 [B][V], V <= 65536,
+ * V % 8 == 0), row list `rows` (indices into logits / ids).  Semantics of
+ * sample_logits_rwkv_pip_compatible (chirrup/utils/samplers.py:171-255): softmax, drop everything below
+ * the probability at which the descending cumulative sum reaches top_p, optional top-k, probs**(1/T), one
+ * draw.  temperature / top_p binary16 and top_k int32 are per-slot tables addressed through slot_idx[row]
+ * (or row); uniform[i] in [0,1) is the random number for rows[i]; ids[rows[i]] receives the token.
+ * Ties at the top-k boundary are all kept; the draw is an inverse-CDF walk in token order.
+ */
+int rwkv7_sample_topp(int n_rows, int V, const void *logits, const int32_t *rows, const void *temperature,
+                      const void *top_p, const int32_t *top_k, const int32_t *slot_idx, const float *uniform,
+                      int32_t *ids, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,55 @@ def test_worker_end_to_end_matches_unbatched_greedy():
     got0 = [x[1][0] for x in tasks[0].output_queue.items if x[0] == "token_generated"]
     got1 = [x[1][0] for x in tasks[1].output_queue.items if x[0] == "token_generated"]
     assert got0 == d["greedy:ids"][0].tolist() and got1 == d["greedy:ids"][1].tolist()
+
+
+@pytest.mark.parametrize("V,temp,top_p,top_k", [(1024, 1.0, 0.3, 0), (1024, 1.0, 0.9, 0), (4096, 1.5, 1.0, 5), (65536, 0.7, 0.8, 10),
+                                                (1024, 1.0, 0.0, 0), (1024, 1.0, 1.0, 1)])
+def test_sample_topp_distribution(V, temp, top_p, top_k):
+    """The sort-free sampler draws from the distribution the reference's algorithm defines
+    (softmax -> top-p cutoff by value -> top-k -> p**(1/T)); frequencies over 20 000 draws match it to
+    the reference's own statistical bar (tests/test_sampler_equivalence.py:110-143: 0.05; here 0.02),
+    nothing outside the kept set is ever drawn, and the greedy corner cases return the arg-max."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(V + int(top_p * 100) + top_k)
+    N = 20000
+    logits = (torch.randn(1, V) * 2.5).half().cuda()
+    p = torch.softmax(logits.float(), -1)[0].cpu()
+    sp, order = torch.sort(p, descending=True)
+    cs = torch.cumsum(sp, 0)
+    cut = sp[min(int(torch.searchsorted(cs, torch.tensor(float(torch.tensor(top_p).half())))), V - 1)]
+    q = torch.where(p < cut, torch.zeros_like(p), p)
+    if top_k > 0:
+        kth = sp[top_k - 1]
+        q = torch.where(p < kth, torch.zeros_like(q), q)          # ties at the boundary are kept (documented)
+    if temp != 1.0:
+        q = q ** (1.0 / temp)
+    q = q / q.sum()
+    rows = torch.zeros(N, dtype=torch.int32, device="cuda")
+    u = torch.rand(N, device="cuda")
+    t = torch.full((1,), temp, dtype=torch.float16, device="cuda")
+    tp = torch.full((1,), top_p, dtype=torch.float16, device="cuda")
+    tk = torch.full((1,), top_k, dtype=torch.int32, device="cuda")
+    # N blocks on the same row, each with its own uniform; every block writes ids[0] -> give each its own row
+    big = logits.expand(N, V).contiguous() if V <= 4096 else None
+    if big is not None:
+        rows = torch.arange(N, dtype=torch.int32, device="cuda")
+        ids = torch.full((N,), -1, dtype=torch.int32, device="cuda")
+        ops.sample_topp(big, rows, t.expand(N).contiguous(), tp.expand(N).contiguous(), tk.expand(N).contiguous(), u, ids)
+        draws = ids.cpu().long()
+    else:
+        draws = []
+        ids = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+        for i in range(400):
+            ops.sample_topp(logits, rows[:1], t, tp, tk, u[i:i + 1], ids)
+            draws.append(int(ids[0]))
+        draws = torch.tensor(draws)
+        N = 400
+    assert int(draws.min()) >= 0
+    freq = torch.bincount(draws, minlength=V).float() / N
+    assert float(freq[q == 0].sum()) == 0.0
+    if N >= 20000:
+        assert float((freq - q).abs().max()) <= 0.02
+    if top_p == 0.0 or top_k == 1:
+        assert bool((draws == int(p.argmax())).all())

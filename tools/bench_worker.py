@@ -12,7 +12,7 @@ from chirrup_amd.worker import Worker
 name = sys.argv[1] if len(sys.argv) > 1 else "7.2B"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 new = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-pen = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+pen = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # 0: greedy, no penalties; 1: greedy + penalties; 2: the reference's DEFAULT sampling config
 L, C = CONFIGS[name]
 dev = torch.device("cuda", 0)
 zd = make_state_dict(L, C, 65536, seed=42, device=dev)
@@ -42,8 +42,8 @@ g = torch.Generator().manual_seed(1234)
 tasks = []
 for i in range(N):
     t = Task(output_queue=Sink(), task_event_queue=queue.Queue(), prompt_str="", prefill_tokens=torch.randint(1, 65536, (4,), generator=g).tolist(),
-             state=None, temperature=0.0 if not pen else 1.0, top_p=0.0 if not pen else 0.0, frequency_penalty=0.5 * pen, presence_penalty=0.5 * pen,
-             penalty_decay=0.996, stop_tokens=[], max_tokens=new)
+             state=None, temperature=0.0 if not pen else 1.0, top_p=0.3 if pen == 2 else 0.0, frequency_penalty=0.5 * min(pen, 1),
+             presence_penalty=0.5 * min(pen, 1), penalty_decay=0.996, stop_tokens=[], max_tokens=new)
     tasks.append(t)
     tq.put(t)
 for _ in range(8):               # admission + the 3 single-token prefill steps + graph capture
@@ -58,4 +58,4 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 n1 = sum(t.output_queue.n for t in tasks)
 print(f"worker {name}: {N} requests, {n1 - n0} tokens in {dt:.3f}s over {steps} iterations -> {(n1 - n0) / dt:.0f} tok/s, "
-      f"{dt / steps * 1e3:.2f} ms/iteration, {(n1 - n0) / dt / N:.1f} tps/request (penalties {'on' if pen else 'off'})")
+      f"{dt / steps * 1e3:.2f} ms/iteration, {(n1 - n0) / dt / N:.1f} tps/request (mode {pen}: {['greedy', 'greedy+penalties', 'default sampling config (T=1, top_p=0.3, penalties)'][pen]})")
