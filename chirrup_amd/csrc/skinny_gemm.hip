@@ -204,6 +204,128 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant (binary16 weights): BOTH operands reach LDS by LDS-DMA into a 3-deep ring, so no load
+// of the main loop has a register destination -- hipcc inserts no vmcnt wait of its own, and the
+// hand-placed counted waits keep two whole K-blocks (2 x 44 KiB at M = 200) in flight per workgroup
+// across raw barriers.  Same tiles, swizzle and MFMA schedule as above; W fragments are read from
+// the ring like the x fragments.
+template <int MT, int EPI>
+__global__ __launch_bounds__(kThreads) void skinny_gemm_ring_kernel(
+    const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
+    const f16 *__restrict__ W, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
+    const f16 *__restrict__ bias, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int kXBytes = MT * 32 * 128;            // x K-block image
+    constexpr int kWBytes = kBN * 128;                // W K-block image: 128 rows x 64 k
+    constexpr int kSlot = kXBytes + kWBytes;
+    constexpr int kPerStage = MT + 4;                 // LDS-DMA instructions per lane per stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_base = blockIdx.x * kBN;
+    const int n0 = n_base + wave * 32;
+    const bool wave_live = n0 < N;
+    const int k_begin = blockIdx.y * k_slice;
+    const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
+    const int nkb = (k_end - k_begin) / kKB;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+
+    auto stage = [&](int kb, int slot) {
+        const int k0 = k_begin + kb * kKB;
+        unsigned char *base = smem + slot * kSlot;
+#pragma unroll
+        for (int i = 0; i < MT; i++) {                 // x image
+            const int g = i * kThreads + tid;
+            int m = g >> 3;
+            const int lc = (g & 7) ^ ((m >> 1) & 7);
+            m = m < M ? m : M - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(X + (int64_t)m * ldx + k0 + lc * 8),
+                                             (lptr_t)(base + (i * kThreads + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                  // W image (weights: streamed once -> nt)
+            const int g = i * kThreads + tid;
+            const int nr = g >> 3;
+            const int lc = (g & 7) ^ ((nr >> 1) & 7);
+            int n = n_base + nr;
+            n = n < N ? n : N - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t)(W + (int64_t)n * ldw + k0 + lc * 8),
+                                             (lptr_t)(base + kXBytes + (i * kThreads + wave * 64) * 16), 16, 0, 2);
+        }
+    };
+    auto compute = [&](int slot) {
+        const unsigned char *xt = smem + slot * kSlot;
+        const unsigned char *wt = xt + kXBytes;
+        const int wr = wave * 32 + r;
+        f16x8 wf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + wr * 128 + (((4 * h + s) ^ ((wr >> 1) & 7)) << 4));
+        auto bfrag = [&](int s, int mt) {
+            const int m = mt * 32 + r;
+            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
+        };
+        f16x8 b0[MT], b1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(0, mt);
+#pragma unroll
+        for (int s = 0; s < 4; s += 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) b1[mt] = bfrag(s + 1, mt);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b0[mt], acc[mt], 0, 0, 0);
+            if (s + 2 < 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(s + 2, mt);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s + 1], b1[mt], acc[mt], 0, 0, 0);
+        }
+    };
+
+    if (nkb > 0) stage(0, 0);
+    if (nkb > 1) stage(1, 1);
+    for (int kb = 0; kb < nkb; kb++) {
+        // queue (issue order): stage kb, stage kb+1.  Retire stage kb only.
+        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");        // every wave's share landed; slot (kb+2)%3 no longer read
+        if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
+        compute(kb % 3);
+    }
+
+    if (!wave_live) return;
+    // acc[mt][i]: m = mt*32 + (lane & 31), n = n0 + 8*(i>>2) + 4*h + (i&3)
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int m = mt * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int n = n0 + 8 * g + 4 * h;
+            if (n >= N) continue;
+            if (EPI == EPI_F16) {
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float v = acc[mt][4 * g + e];
+                    if (bias) v += (float)bias[n + e];
+                    o[e] = (f16)v;
+                }
+                *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+            } else {
+                const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(part + ((int64_t)blockIdx.y * M + m) * N + n) = o;
+            }
+        }
+    }
+}
+
+
 // Sum the split-K partials and apply the epilogue.
 //   mode 0: y = sum (+ bias[n]);  mode 1: y = relu(sum (+bias))^2;
 //   mode 2 (mm8): y = rx[n]*(sum + 0.5*S[m][0]) + S[m][1] + mx[n]*S[m][2]      (benchmark.py:167-179)
@@ -302,6 +424,8 @@ int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, i
     return (int)hipGetLastError();
 }
 
+bool g_use_ring = true;     // binary16 weights: LDS-DMA ring kernel (false: register-staged kernel)
+
 int pick_splits(int N, int K, int requested) {
     if (requested > 0) return requested;
     const int ngroups = (N + kBN - 1) / kBN;
@@ -314,6 +438,31 @@ int pick_splits(int N, int K, int requested) {
 }
 
 }  // namespace
+
+template <int EPI>
+int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const f16 *W,
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+    const size_t lds = (size_t)3 * (MT * 32 * 128 + kBN * 128);
+#define GO(MTV)                                                                                                           \
+    do {                                                                                                                  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_ring_kernel<MTV, EPI>),                      \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+        hipLaunchKernelGGL((skinny_gemm_ring_kernel<MTV, EPI>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X, ldx, W, \
+                           ldw, Y, ldy, bias, part);                                                                      \
+    } while (0)
+    switch (MT) {
+        case 1: GO(1); break;
+        case 2: GO(2); break;
+        case 3: GO(3); break;
+        case 4: GO(4); break;
+        case 5: GO(5); break;
+        case 6: GO(6); break;
+        case 7: GO(7); break;
+        default: GO(8); break;
+    }
+#undef GO
+    return (int)hipGetLastError();
+}
 
 extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -337,7 +486,14 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((N + kBN - 1) / kBN, s);
     const size_t lds = (size_t)2 * MT * 32 * 128;
-    int rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+    int rc;
+    if (g_use_ring)
+        rc = partial ? launch_ring<EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, (const f16 *)W, ldw, (f16 *)Y,
+                                                ldy, (const f16 *)bias, (float *)workspace)
+                     : launch_ring<EPI_F16>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, (const f16 *)W, ldw, (f16 *)Y, ldy,
+                                            (const f16 *)bias, (float *)workspace);
+    else
+        rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                            (const f16 *)bias, (float *)workspace);
     if (rc) return rc;
     if (partial) {
@@ -392,3 +548,5 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
                        nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2, (f16 *)y, y_stride);
     return (int)hipGetLastError();
 }
+
+extern "C" void skinny_gemm_select(int use_ring) { g_use_ring = use_ring != 0; }

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "skinny_gemm_select": (None, [_i]),
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -164,6 +164,7 @@ class RWKV_x070:
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
+        self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -421,6 +422,10 @@ class RWKV_x070:
                 ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
+                elif self.skinny_ffn_value and 128 < rows <= 256 and C >= 4096:
+                    # K = 4C >> N = C at decode batch sizes: the hand-written LDS-DMA ring GEMM streams this
+                    # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200)
+                    delta = ops.skinny_linear(kf.view(rows, 4 * C), lw.f_V.t(), splits=8).view(B, T, C)
                 else:
                     delta = kf @ lw.f_V
         if T > 1 and not full_output:

@@ -157,6 +157,8 @@ int rwkv7_relu_sq(int64_t n, void *x, void *stream);
  * device scratch when that is > 0 or act != 0.
  */
 int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
+/* 1 (default): both operands through a 3-deep LDS-DMA ring; 0: register-staged variant. (A/B switch.) */
+void skinny_gemm_select(int use_ring);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
                     void *Y, int ldy, int act, int splits, void *workspace, void *stream);
 
