@@ -59,7 +59,8 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 // If x_out != nullptr the summed row is stored there.
 __device__ __forceinline__ void ln_row(const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
                                        const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
-                                       float (&out)[kLnMaxChunks][8], float *red) {
+                                       float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
+                                       int dsplits = 0, int64_t dsplit_stride = 0) {
     const int nchunk = C >> 3;
     float vals[kLnMaxChunks][8];
     float s = 0.f;
@@ -68,7 +69,17 @@ __device__ __forceinline__ void ln_row(const f16 *__restrict__ x, const f16 *__r
         const int c = threadIdx.x + q * kLnThreads;
         if (c < nchunk) {
             f16x8 xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
-            if (delta) {
+            if (dpart) {            // delta = binary16(sum of split-K partials): the GEMM's reduce folded into this prologue
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int sidx = 0; sidx < dsplits; sidx++) {
+                    const float4 p0 = *reinterpret_cast<const float4 *>(dpart + sidx * dsplit_stride + c * 8);
+                    const float4 p1 = *reinterpret_cast<const float4 *>(dpart + sidx * dsplit_stride + c * 8 + 4);
+                    acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
+                    acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)h(acc[e]));
+            } else if (delta) {
                 const f16x8 dv = *reinterpret_cast<const f16x8 *>(delta + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)dv[e]);
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int T, const int C, const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
-    const int32_t *__restrict__ slot_idx) {
+    const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride) {
     __shared__ float red[kLnThreads / 64];
     const int row = blockIdx.x;
     const int bb = row / T, t = row - bb * T;
@@ -121,7 +132,8 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int nchunk = C >> 3;
     const int64_t ro = (int64_t)row * C;
     float cur[kLnMaxChunks][8];
-    ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red);
+    ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
+           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride);
     if (NMIX == 0) {
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++) {
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
             }
         }
     } else {
-        ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red);
+        ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red,
+               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride);
     }
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
@@ -304,19 +317,22 @@ inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                                 const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
                                 const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
-                                void *stream) {
+                                const float *delta_partials, int delta_splits, void *stream) {
     if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
     if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;
     if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
     if (n_mix > 0 && (!prev_in || !prev_out || !mix)) return CHIRRUP_E_NULL;
     if (n_mix > 0 && T > 1 && prev_in == prev_out) return CHIRRUP_E_UNSUPPORTED;  // rows race on the carry
+    if (delta_partials && (delta || delta_splits <= 0)) return CHIRRUP_E_UNSUPPORTED;
+    if (mis16(delta_partials)) return CHIRRUP_E_ALIGN;
     if (mis16(x) || mis16(delta) || mis16(x_out) || mis16(ln_w) || mis16(ln_b) || mis16(prev_in) || mis16(prev_out) ||
         mis16(mix) || mis16(out) || (out_stride & 7))
         return CHIRRUP_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(B * T)), block(kLnThreads);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
-             (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx
+             (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx, delta_partials, \
+             delta_splits, (int64_t)B * T * C
     if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
     else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
     else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);

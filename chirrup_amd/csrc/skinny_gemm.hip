@@ -505,6 +505,21 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     return rc;
 }
 
+extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
+                                       float *partials, void *stream) {
+    if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7))
+        return CHIRRUP_E_SHAPE;
+    if (!X || !W || !partials) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(partials) & 15))
+        return CHIRRUP_E_ALIGN;
+    const int s = pick_splits(N, K, splits);
+    const int MT = (M + 31) / 32;
+    const dim3 grid((N + kBN - 1) / kBN, s);
+    const int rc = launch_ring<EPI_PARTIAL>(MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
+                                            (const f16 *)W, ldw, nullptr, N, nullptr, partials);
+    return rc ? -1000 - rc : s;
+}
+
 // mm8 with K-contiguous ("packed", [M_out][N_in]) uint8 weights.  Same quantisation and formula as
 // mm8_seq; evaluated in the split form: xs = fp16(x*ry) through MFMA, rank-1 corrections after.
 // workspace layout: xs [B][N_in] f16 | S [B][3] f32 | partials [splits][B][M_out] f32

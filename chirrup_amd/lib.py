@@ -29,7 +29,7 @@ SIGNATURES = {
     "mm8_seq_workspace_bytes": (_i64, [_i, _i, _i]),
     "mm8_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mm8_one": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f32p, _vp]),
-    "rwkv7_add_ln_mix": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "rwkv7_add_ln_mix": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "rwkv7_tmix_mid": (_i, [_i64, _i] + [_vp] * 9 + [_vp]),
     "rwkv7_tmix_post": (_i, [_i64, _i] + [_vp] * 8 + [ctypes.c_float, _vp, _vp]),
     "rwkv7_relu_sq": (_i, [_i64, _vp, _vp]),
@@ -39,6 +39,7 @@ SIGNATURES = {
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "skinny_gemm_select": (None, [_i]),
+    "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp]),
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

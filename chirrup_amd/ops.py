@@ -161,7 +161,7 @@ def _chk16(name, t, numel=None):
 
 
 def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out,
-               slot_idx=None) -> None:
+               slot_idx=None, delta_partials=None) -> None:
     """x_new = x (+delta) -> x_out; cur = LN(x_new); out[m] = cur + (shifted - cur) * mix[m]
     (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h."""
     n_mix = 0 if mix is None else mix.shape[0]
@@ -178,9 +178,15 @@ def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, 
             _chk(slot_idx, "slot_idx", torch.int32, (B,))
             if prev_in.numel() % C or prev_out.numel() != prev_in.numel():
                 raise _lib.ChirrupAmdError("prev tables must be [n_slots, C]")
+    dsplits = 0
+    if delta_partials is not None:        # fp32 [splits, B*T, C] from skinny_linear_partial; replaces `delta`
+        if delta is not None or delta_partials.dtype != torch.float32 or not delta_partials.is_contiguous() \
+                or delta_partials.numel() % (B * T * C):
+            raise _lib.ChirrupAmdError("delta_partials: expected contiguous fp32 [splits, B*T, C] and delta=None")
+        dsplits = delta_partials.numel() // (B * T * C)
     rc = _lib.load().rwkv7_add_ln_mix(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
                                       _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _ptr(slot_idx),
-                                      _stream())
+                                      _ptr(delta_partials), dsplits, _stream())
     _lib.check(rc, "rwkv7_add_ln_mix")
 
 
@@ -282,6 +288,24 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None)
                            out.data_ptr(), out.stride(0), act, splits, _ptr(ws), _stream())
     _lib.check(rc, "skinny_gemm_f16")
     return out
+
+
+def skinny_linear_partial(x, weight, splits: int, partials):
+    """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
+    [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if partials.dtype != torch.float32 or not partials.is_contiguous():
+        raise _lib.ChirrupAmdError("partials: expected contiguous fp32")
+    L = _lib.load()
+    want = L.skinny_gemm_workspace_bytes(M, N, K, splits) or M * N * 4
+    if partials.numel() * 4 < want:
+        raise _lib.ChirrupAmdError("partials buffer too small")
+    rc = L.skinny_gemm_f16_partial(M, N, K, x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), splits,
+                                   partials.data_ptr(), _stream())
+    if rc <= 0:
+        raise _lib.ChirrupAmdError(f"skinny_gemm_f16_partial: {rc}")
+    return partials.view(-1)[: rc * M * N].view(rc, M, N)
 
 
 def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None):

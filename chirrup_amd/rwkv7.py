@@ -165,6 +165,7 @@ class RWKV_x070:
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
+        self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -359,6 +360,10 @@ class RWKV_x070:
             y, neg_kk, kka = new(B, T, C), new(B, T, C), new(B, T, C)
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
+        dparts = None                     # split-K partials of the previous ffn.value GEMM (summed by the next LN kernel)
+        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and 128 < rows <= 256
+                     and C >= self.skinny_min_embd)
+        pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
 
         def commit_carry(prev):
             if slot_idx is None:
@@ -372,8 +377,8 @@ class RWKV_x070:
                     raise ops._lib.ChirrupAmdError("state[0][layer][j] view must be contiguous (slice the batch dim only)")
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
-            ops.add_ln_mix(B, T, C, x, delta, x if delta is not None else None, lw.ln1_w, lw.ln1_b, 1e-5, prev,
-                           prev if T == 1 else carry, lw.mix6, mixed, slot_idx)
+            ops.add_ln_mix(B, T, C, x, delta, x if (delta is not None or dparts is not None) else None, lw.ln1_w, lw.ln1_b,
+                           1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts)
             if T > 1:
                 commit_carry(prev)
             # planes: 0 r, 1 k, 2 v, 3 w, 4 a, 5 g
@@ -422,19 +427,22 @@ class RWKV_x070:
                 ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
-                elif self.skinny_ffn_value and 128 < rows <= 256 and C >= 4096:
+                elif use_parts:
                     # K = 4C >> N = C at decode batch sizes: the hand-written LDS-DMA ring GEMM streams this
-                    # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200)
-                    delta = ops.skinny_linear(kf.view(rows, 4 * C), lw.f_V.t(), splits=8).view(B, T, C)
+                    # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200);
+                    # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
+                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V.t(), 8, pbuf), None
                 else:
                     delta = kf @ lw.f_V
+        if dparts is not None and (T > 1 and not full_output):
+            delta, dparts = dparts.sum(0).to(DTYPE).view(B, T, C), None      # e.g. B=2, T=100: only the last rows are needed
         if T > 1 and not full_output:
             x, delta, rows_out = x[:, -1, :].contiguous(), delta[:, -1, :].contiguous(), (B, 1)
         else:
             rows_out = (B, T)
         xo = new(rows_out[0], rows_out[1], C)
         ops.add_ln_mix(rows_out[0], rows_out[1], C, x, delta, None, z["ln_out.weight"], z["ln_out.bias"], 1e-5, None, None,
-                       None, xo)
+                       None, xo, delta_partials=dparts)
         if not full_output:
             xo = xo.view(B, C)
         if slot_idx is not None:

@@ -104,11 +104,15 @@ int mm8_one(int N, int M, const void *x, const void *w, int w_stride, const void
  *   the last row; with n_mix == 0: out = cur.   x,delta,x_out,out[m]: [B][T][C]; prev_*: [B][C];
  *   mix: [n_mix][C]; out planes are out_stride elements apart.  T > 1 needs prev_out != prev_in.
  *   slot_idx (may be NULL): batch row b carries its token-shift state in row slot_idx[b] of prev_*.
+ *   delta_partials (may be NULL; then delta must be NULL): float [delta_splits][B][T][C] split-K partial sums of
+ *   the GEMM that produced delta (skinny_gemm_f16_partial); delta = binary16(sum over splits) is formed in this
+ *   kernel's prologue, saving the GEMM's separate reduce launch.
  *   Replaces rwkv7.py:523 + :621-623 (n_mix 6), :531-533 + :675-677 (n_mix 1), :548-550 (n_mix 0).
  */
 int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                      const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
-                     const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx, void *stream);
+                     const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
+                     const float *delta_partials, int delta_splits, void *stream);
 
 /* rwkv7.py:629-637: a = sigmoid(a_pre); kk = normalize(k*k_k) per 64-channel head;
  * k <- k*(1+(a-1)*k_a) in place; neg_kk = -kk; kka = kk*a; and, when v_first != NULL (layer > 0),
@@ -157,6 +161,11 @@ int rwkv7_relu_sq(int64_t n, void *x, void *stream);
  * device scratch when that is > 0 or act != 0.
  */
 int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
+/* As skinny_gemm_f16 without bias/activation, but leaves the `splits` binary32 partial results
+ * [splits][M][N] in `partials` for the consumer to sum (see rwkv7_add_ln_mix). Returns the split count used
+ * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
+int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
+                            float *partials, void *stream);
 /* 1 (default): both operands through a 3-deep LDS-DMA ring; 0: register-staged variant. (A/B switch.) */
 void skinny_gemm_select(int use_ring);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,

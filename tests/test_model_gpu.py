@@ -201,3 +201,26 @@ def test_bszless_decode_does_not_corrupt_the_embedding_table():
         m.forward(tok, st)
         m.forward([tok], st)
     assert torch.equal(m.z["emb.weight"], emb)
+
+
+@pytest.mark.parametrize("B,T", [(130, 1), (3, 60)])
+def test_skinny_ffn_value_with_reduce_folded_into_next_ln(B, T):
+    """ffn.value through the hand-written ring GEMM, its split-K partials summed in the prologue of the
+    next add_ln_mix (no reduce launch): same logits/state as the library-GEMM path to fp16 noise."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    args = lambda: types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
+    ma, mb = RWKV_x070(args(), state_dict=zd, device="cuda:0"), RWKV_x070(args(), state_dict=zd, device="cuda:0")
+    ma.skinny_min_embd = 0            # force the path on this tiny model (production: C >= 4096)
+    mb.skinny_ffn_value = False
+    rng = np.random.default_rng(B)
+    toks = rng.integers(1, 320, size=(B, T)).tolist()
+    sa, sb = ma.generate_zero_state(B), mb.generate_zero_state(B)
+    for _ in range(2):
+        la = ma.forward_seq_batch_seperate(toks, sa)
+        lb = mb.forward_seq_batch_seperate(toks, sb)
+        assert rel_linf(la.cpu().numpy(), lb.cpu().numpy()) <= 2e-3
+        assert rel_linf(sa[1].cpu().numpy(), sb[1].cpu().numpy()) <= 2e-3
+        assert rel_linf(sa[0].cpu().numpy(), sb[0].cpu().numpy()) <= 2e-3
