@@ -120,7 +120,7 @@ def recorded_traffic(B, C, fused=False):
     WRITE_SIZE in separate runs, gfx950 correction applied) -- only when they were taken at this shape."""
     import glob
 
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*wkv7_pmc_traffic.json")), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
         rec = json.load(open(f))
         if ("<1>" in rec["kernel"]) != fused:
             continue
