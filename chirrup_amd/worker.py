@@ -153,8 +153,11 @@ class Worker:
 
     @staticmethod
     def _is_task_aborted(td) -> bool:
+        q = td["task"].task_event_queue
+        if q.empty():                       # the common case, without the cost of raising queue.Empty
+            return False
         try:
-            kind, _ = td["task"].task_event_queue.get_nowait()
+            kind, _ = q.get_nowait()
             return kind == "abort"
         except queue.Empty:
             return False
@@ -290,12 +293,19 @@ class Worker:
         if not slots:
             return
         idx = self._slot_tensor(slots)
+        nd = len(decode_slots)
+        # every small host->device tensor is created BEFORE the forward is enqueued: a pageable H2D copy is
+        # synchronous and would otherwise stall the host behind the whole decode step
+        sampled = [j for j, s in enumerate(decode_slots) if not self._greedy[s]]
+        rows = u = None
+        if sampled:
+            rows = torch.tensor(sampled, device=self.device, dtype=torch.int32)
+            u = torch.rand((len(sampled),), device=self.device, dtype=torch.float32)
         if self.use_graph:
             out = self._graph_for(len(slots)).run([self.state_slot[s]["next_input_token"] for s in slots], slots)
         else:
             tokens = [[self.state_slot[s]["next_input_token"]] for s in slots]
             out = self.model.forward_slots(tokens, self.batch_state, idx)
-        nd = len(decode_slots)
         if nd == 0:
             return
         logits = out[:nd]
@@ -308,20 +318,17 @@ class Worker:
         didx = idx[:nd]
         # penalties for every decode row + arg-max, one kernel; occurrence is decayed in place
         ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
-                                  self.frequency_penalty_tensor.view(-1), didx)
-        sampled = [j for j, s in enumerate(decode_slots) if not self._greedy[s]]
+                                    self.frequency_penalty_tensor.view(-1), didx)
         if sampled:
             if self._sample_topp is not None and logits.shape[1] <= 65536:
                 # sort-free top-p / top-k / temperature kernel, one workgroup per sampled row
-                rows = torch.tensor(sampled, device=self.device, dtype=torch.int32)
-                u = torch.rand((len(sampled),), device=self.device, dtype=torch.float32)
                 self._sample_topp(logits, rows, self.temperature_tensor.view(-1), self.top_p_tensor.view(-1),
                                   self.top_k_tensor.view(-1), u, ids, didx)
             else:
-                rows = torch.tensor(sampled, device=self.device, dtype=torch.long)
-                srows = didx.long()[rows]
-                ids[rows] = sample_logits_rwkv_pip_compatible(logits[rows], self.temperature_tensor[srows],
-                                                              self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
+                lrows = rows.long()
+                srows = didx.long()[lrows]
+                ids[lrows] = sample_logits_rwkv_pip_compatible(logits[lrows], self.temperature_tensor[srows],
+                                                               self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
         host_ids = ids.tolist()                  # ONE device->host copy for the whole batch
         for j, s in enumerate(decode_slots):
             self.state_slot[s]["new_token"] = int(host_ids[j])
