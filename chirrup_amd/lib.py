@@ -8,12 +8,14 @@ and torch's stream handles are valid for our launches.
 import ctypes
 import os
 import subprocess
+import threading
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchirrup_amd.so")
 _lib = None
+_lock = threading.Lock()      # worker threads may race to the first load
 
 E_NAMES = {-1: "CHIRRUP_E_SHAPE", -2: "CHIRRUP_E_NULL", -3: "CHIRRUP_E_ALIGN", -4: "CHIRRUP_E_UNSUPPORTED"}
 
@@ -61,7 +63,11 @@ def build(force: bool = False) -> str:
 def load():
     """Return the ctypes handle; raises ChirrupAmdError when the library is not built."""
     global _lib
-    if _lib is None:
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise ChirrupAmdError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
