@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
+    p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
@@ -202,6 +204,11 @@ def main():
     L, C = CONFIGS[a.model]
     B = a.bsz
     model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8)
+    if a.gemm_mode is not None:
+        from chirrup_amd import lib
+        lib.load().skinny_gemm_select(a.gemm_mode)
+    if a.skinny_key is not None:
+        model.skinny_ffn_key = bool(a.skinny_key)
     state = make_state(model, B)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)

@@ -63,6 +63,17 @@ struct WRaw {
     u32x4 q[W8 ? 2 : 4];
 };
 
+// Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
+// own L2: give XCD j a contiguous run of the K-slice-major tile order, so the x K-slice a workgroup re-reads is shared
+// by its L2 neighbours (ffn.value at bsz 200: x is 6.5 MB, a K-slice 0.8 MB; the L2 is 4 MB).
+__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice) {
+    const int G = gridDim.x, total = G * gridDim.y;
+    const int L = blockIdx.x + G * blockIdx.y;
+    const int v = (total & 7) ? L : (L & 7) * (total >> 3) + (L >> 3);
+    kslice = v / G;
+    ngroup = v - kslice * G;
+}
+
 template <int MT, bool W8, int EPI>
 __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
@@ -72,9 +83,11 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
     constexpr int kTileBytes = MT * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int n0 = (blockIdx.x * 4 + wave) * 32;
+    int ngroup, kslice;
+    tile_of_block(ngroup, kslice);
+    const int n0 = (ngroup * 4 + wave) * 32;
     const bool wave_live = n0 < N;
-    const int k_begin = blockIdx.y * k_slice;
+    const int k_begin = kslice * k_slice;
     const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
     const int nkb = (k_end - k_begin) / kKB;
 
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
                 *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
             } else {
                 const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(part + ((int64_t)blockIdx.y * M + m) * N + n) = o;
+                *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * N + n) = o;
             }
         }
     }
@@ -210,24 +223,54 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
 // hand-placed counted waits keep two whole K-blocks (2 x 44 KiB at M = 200) in flight per workgroup
 // across raw barriers.  Same tiles, swizzle and MFMA schedule as above; W fragments are read from
 // the ring like the x fragments.
-template <int MT, int EPI>
-__global__ __launch_bounds__(kThreads) void skinny_gemm_ring_kernel(
+// s_waitcnt vmcnt(ahead * PER): leave the `ahead` youngest stages (PER LDS-DMA instructions each) in flight
+template <int PER>
+__device__ __forceinline__ void wait_stages_ahead(const int ahead) {
+#define WAIT_CASE(A)                                                                  \
+    case A:                                                                           \
+        if constexpr ((A) * PER <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * PER) : "memory"); \
+        break;
+    switch (ahead) {
+        WAIT_CASE(7) WAIT_CASE(6) WAIT_CASE(5) WAIT_CASE(4) WAIT_CASE(3) WAIT_CASE(2) WAIT_CASE(1)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef WAIT_CASE
+}
+
+// Both operands through LDS-DMA rings; four waves compute (32 W rows x MT*32 x rows each).  Who issues the loads (RM):
+//   0: every compute wave loads its share of x and W; one ring of XD (== WD) slots.
+//   1: waves 0-1 load x (L2-resident, XD slots), waves 2-3 load W (HBM, WD slots): vmcnt counts per wave and retires
+//      in order, so only a wave that issues nothing but W loads can keep WD-1 weight stages in flight without also
+//      waiting for the x stage issued after them.
+//   2: four extra loader waves (one per SIMD, 512-thread workgroup) issue everything: a wave is blocked while its
+//      LDS-DMA instructions issue (~0.15 us per 16 KiB), which the compute waves then spend in MFMAs instead.
+template <int MT, bool W8, int EPI, int XD, int WD, int RM>
+__global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
-    const f16 *__restrict__ W, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
+    const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
     const f16 *__restrict__ bias, float *__restrict__ part) {
+    static_assert(RM == 1 || XD == WD, "one ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kXBytes = MT * 32 * 128;            // x K-block image
-    constexpr int kWBytes = kBN * 128;                // W K-block image: 128 rows x 64 k
-    constexpr int kSlot = kXBytes + kWBytes;
-    constexpr int kPerStage = MT + 4;                 // LDS-DMA instructions per lane per stage
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWBytes = kBN * (W8 ? 64 : 128);    // W K-block image: 128 rows x 64 k (binary16 or uint8)
+    constexpr int kLanes = RM == 1 ? 128 : 256;       // lanes that load one operand
+    constexpr int kXLoads = kXBytes / 16 / kLanes;    // LDS-DMA instructions per loading lane per stage
+    constexpr int kWLoads = kWBytes / 16 / kLanes;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int n_base = blockIdx.x * kBN;
+    const bool computes = wave < 4;
+    const bool loads_x = RM == 0 || (RM == 1 ? wave < 2 : wave >= 4), loads_w = RM == 0 || (RM == 1 ? wave >= 2 : wave >= 4);
+    const int lt = RM == 1 ? (tid & 127) : (tid & 255), lw = RM == 1 ? (wave & 1) : (wave & 3);
+    int ngroup, kslice;
+    tile_of_block(ngroup, kslice);
+    const int n_base = ngroup * kBN;
     const int n0 = n_base + wave * 32;
-    const bool wave_live = n0 < N;
-    const int k_begin = blockIdx.y * k_slice;
+    const bool wave_live = computes && n0 < N;
+    const int k_begin = kslice * k_slice;
     const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
     const int nkb = (k_end - k_begin) / kKB;
+    unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -235,67 +278,111 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_ring_kernel(
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
 
-    auto stage = [&](int kb, int slot) {
-        const int k0 = k_begin + kb * kKB;
-        unsigned char *base = smem + slot * kSlot;
+#ifndef SKINNY_EXP
+#define SKINNY_EXP 0   // ingest experiments (tools/exp_skinny_ingest.py): 1/2 = W / x always from the slice's first K-block,
+#endif                 // 4 = no MFMA, 8 = one x fragment per step
+    auto stage_x = [&](int kb) {
+        const int k0 = k_begin + ((SKINNY_EXP & 2) ? 0 : kb * kKB);
+        unsigned char *base = xring + (kb % XD) * kXBytes;
 #pragma unroll
-        for (int i = 0; i < MT; i++) {                 // x image
-            const int g = i * kThreads + tid;
+        for (int i = 0; i < kXLoads; i++) {
+            const int g = i * kLanes + lt;
             int m = g >> 3;
             const int lc = (g & 7) ^ ((m >> 1) & 7);
             m = m < M ? m : M - 1;
             __builtin_amdgcn_global_load_lds((gptr_t)(X + (int64_t)m * ldx + k0 + lc * 8),
-                                             (lptr_t)(base + (i * kThreads + wave * 64) * 16), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {                  // W image (weights: streamed once -> nt)
-            const int g = i * kThreads + tid;
-            const int nr = g >> 3;
-            const int lc = (g & 7) ^ ((nr >> 1) & 7);
-            int n = n_base + nr;
-            n = n < N ? n : N - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(W + (int64_t)n * ldw + k0 + lc * 8),
-                                             (lptr_t)(base + kXBytes + (i * kThreads + wave * 64) * 16), 16, 0, 2);
+                                             (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 0);
         }
     };
-    auto compute = [&](int slot) {
-        const unsigned char *xt = smem + slot * kSlot;
-        const unsigned char *wt = xt + kXBytes;
+    auto stage_w = [&](int kb) {                       // weights: streamed once -> nt
+        const int k0 = k_begin + ((SKINNY_EXP & 1) ? 0 : kb * kKB);
+        unsigned char *base = wring + (kb % WD) * kWBytes;
+#pragma unroll
+        for (int i = 0; i < kWLoads; i++) {
+            const int g = i * kLanes + lt;
+            if constexpr (W8) {                        // 64-B rows: 4 chunks per row, chunk position ^ ((row>>2)&3)
+                const int nr = g >> 2;
+                const int lc = (g & 3) ^ ((nr >> 2) & 3);
+                int n = n_base + nr;
+                n = n < N ? n : N - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const uint8_t *>(Wv) + (int64_t)n * ldw + k0 + lc * 16),
+                                                 (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
+            } else {
+                const int nr = g >> 3;
+                const int lc = (g & 7) ^ ((nr >> 1) & 7);
+                int n = n_base + nr;
+                n = n < N ? n : N - 1;
+                __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const f16 *>(Wv) + (int64_t)n * ldw + k0 + lc * 8),
+                                                 (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
+            }
+        }
+    };
+    auto compute = [&](int kb) {
+        const unsigned char *xt = xring + (kb % XD) * kXBytes;
+        const unsigned char *wt = wring + (kb % WD) * kWBytes;
         const int wr = wave * 32 + r;
         f16x8 wf[4];
+        if constexpr (W8) {
+            // lane (r,h) needs bytes 32h .. 32h+31 of its row: chunks 2h and 2h+1
+            const int sw = (wr >> 2) & 3;
+            const u32x4 q0 = *reinterpret_cast<const u32x4 *>(wt + wr * 64 + (((2 * h) ^ sw) << 4));
+            const u32x4 q1 = *reinterpret_cast<const u32x4 *>(wt + wr * 64 + (((2 * h + 1) ^ sw) << 4));
 #pragma unroll
-        for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + wr * 128 + (((4 * h + s) ^ ((wr >> 1) & 7)) << 4));
+            for (int s = 0; s < 4; s++) {
+                const uint32_t lo = s < 2 ? q0[2 * s] : q1[2 * (s - 2)];
+                const uint32_t hi = s < 2 ? q0[2 * s + 1] : q1[2 * (s - 2) + 1];
+                const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
+                wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + wr * 128 + (((4 * h + s) ^ ((wr >> 1) & 7)) << 4));
+        }
         auto bfrag = [&](int s, int mt) {
-            const int m = mt * 32 + r;
+            const int m = ((SKINNY_EXP & 8) ? 0 : mt * 32) + r;   // exp 8: one x fragment per step, reused (7x fewer LDS reads)
             return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
         };
-        f16x8 b0[MT], b1[MT];
+#if SKINNY_EXP & 4
+#define MMA(A, B, C) asm volatile("" ::"v"(A), "v"(B))   // exp 4: fragments fetched, no MFMA
+#else
+#define MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
+#endif
+        // x fragments one MFMA group ahead of their use.  The sched_barriers pin that order: left alone, the scheduler
+        // sinks every ds_read to just before its MFMA (fewer live registers) and each MFMA then waits a full LDS latency.
+        f16x8 bq[2][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(0, mt);
+        for (int mt = 0; mt < MT; mt++) bq[0][mt] = bfrag(0, mt);
 #pragma unroll
-        for (int s = 0; s < 4; s += 2) {
+        for (int s = 0; s < 4; s++) {
+            if (s + 1 < 4) {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) b1[mt] = bfrag(s + 1, mt);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b0[mt], acc[mt], 0, 0, 0);
-            if (s + 2 < 4) {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(s + 2, mt);
+                for (int mt = 0; mt < MT; mt++) bq[(s + 1) & 1][mt] = bfrag(s + 1, mt);
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s + 1], b1[mt], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < MT; mt++) MMA(wf[s], bq[s & 1][mt], acc[mt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#undef MMA
     };
 
-    if (nkb > 0) stage(0, 0);
-    if (nkb > 1) stage(1, 1);
+    // at step kb the x queue holds stages kb .. kb+XD-2 and the W queue kb .. kb+WD-2, each in issue order
+#pragma unroll
+    for (int p = 0; p < (XD > WD ? XD : WD) - 1; p++) {
+        if (loads_x && p < XD - 1 && p < nkb) stage_x(p);
+        if (loads_w && p < WD - 1 && p < nkb) stage_w(p);
+    }
     for (int kb = 0; kb < nkb; kb++) {
-        // queue (issue order): stage kb, stage kb+1.  Retire stage kb only.
-        if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPerStage) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");        // every wave's share landed; slot (kb+2)%3 no longer read
-        if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
-        compute(kb % 3);
+        const int left = nkb - 1 - kb;
+        const int ax = left < XD - 2 ? left : XD - 2, aw = left < WD - 2 ? left : WD - 2;   // younger stages already issued
+        if constexpr (RM == 0) wait_stages_ahead<kXLoads + kWLoads>(ax);
+        else if constexpr (RM == 2) { if (!computes) wait_stages_ahead<kXLoads + kWLoads>(ax); }
+        else if (loads_x) wait_stages_ahead<kXLoads>(ax);
+        else wait_stages_ahead<kWLoads>(aw);
+        asm volatile("s_barrier" ::: "memory");        // every wave's share landed; the slots restaged below are no longer read
+        if (loads_x && kb + XD - 1 < nkb) stage_x(kb + XD - 1);
+        if (loads_w && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
+        if (RM != 2 || computes) compute(kb);
     }
 
     if (!wave_live) return;
@@ -319,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_ring_kernel(
                 *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
             } else {
                 const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(part + ((int64_t)blockIdx.y * M + m) * N + n) = o;
+                *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * N + n) = o;
             }
         }
     }
@@ -424,7 +511,7 @@ int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, i
     return (int)hipGetLastError();
 }
 
-bool g_use_ring = true;     // binary16 weights: LDS-DMA ring kernel (false: register-staged kernel)
+int g_mode = 3;             // 0: register-staged kernel; 1-3: LDS-DMA ring kernel variants (launch_ring_mode); 3 measured fastest
 
 int pick_splits(int N, int K, int requested) {
     if (requested > 0) return requested;
@@ -439,16 +526,20 @@ int pick_splits(int N, int K, int requested) {
 
 }  // namespace
 
-template <int EPI>
-int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const f16 *W,
-                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
-    const size_t lds = (size_t)3 * (MT * 32 * 128 + kBN * 128);
+// MODE 1: one ring, every wave loads both operands; 2: x / W loader roles, x 2 slots / W 6 (u8: 8); 3: dedicated loader waves
+template <bool W8, int EPI, int MODE>
+int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
+                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+    constexpr int RM = MODE - 1;
+    constexpr int XD = MODE == 2 ? 2 : (W8 ? 4 : 3);
+    constexpr int WD = MODE == 2 ? (W8 ? 8 : 6) : XD;
+    const size_t lds = (size_t)XD * (MT * 32 * 128) + (size_t)WD * (kBN * (W8 ? 64 : 128));
 #define GO(MTV)                                                                                                           \
     do {                                                                                                                  \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_ring_kernel<MTV, EPI>),                      \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
-        hipLaunchKernelGGL((skinny_gemm_ring_kernel<MTV, EPI>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X, ldx, W, \
-                           ldw, Y, ldy, bias, part);                                                                      \
+        auto kern = skinny_gemm_ring_kernel<MTV, W8, EPI, XD, WD, RM>;                                                    \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                  (int)lds);                                                                              \
+        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);     \
     } while (0)
     switch (MT) {
         case 1: GO(1); break;
@@ -462,6 +553,16 @@ int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_sl
     }
 #undef GO
     return (int)hipGetLastError();
+}
+
+template <bool W8, int EPI>
+int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+    switch (g_mode) {
+        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
+        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
+        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
+    }
 }
 
 extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) {
@@ -487,11 +588,11 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     const dim3 grid((N + kBN - 1) / kBN, s);
     const size_t lds = (size_t)2 * MT * 32 * 128;
     int rc;
-    if (g_use_ring)
-        rc = partial ? launch_ring<EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, (const f16 *)W, ldw, (f16 *)Y,
-                                                ldy, (const f16 *)bias, (float *)workspace)
-                     : launch_ring<EPI_F16>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, (const f16 *)W, ldw, (f16 *)Y, ldy,
-                                            (const f16 *)bias, (float *)workspace);
+    if (g_mode)
+        rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y,
+                                                       ldy, (const f16 *)bias, (float *)workspace)
+                     : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                                                   (const f16 *)bias, (float *)workspace);
     else
         rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                            (const f16 *)bias, (float *)workspace);
@@ -515,8 +616,8 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
     const int s = pick_splits(N, K, splits);
     const int MT = (M + 31) / 32;
     const dim3 grid((N + kBN - 1) / kBN, s);
-    const int rc = launch_ring<EPI_PARTIAL>(MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
-                                            (const f16 *)W, ldw, nullptr, N, nullptr, partials);
+    const int rc = launch_ring<false, EPI_PARTIAL>(MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
+                                                   W, ldw, nullptr, N, nullptr, partials);
     return rc ? -1000 - rc : s;
 }
 
@@ -555,8 +656,10 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
     const int MT = (B + 31) / 32;
     const dim3 grid((M_out + kBN - 1) / kBN, s);
     const size_t lds = (size_t)2 * MT * 32 * 128;
-    int rc = launch<true>(MT, true, grid, lds, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, (f16 *)y, y_stride,
-                          nullptr, part);
+    int rc = g_mode ? launch_ring<true, EPI_PARTIAL>(MT, grid, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride,
+                                                         (f16 *)y, y_stride, nullptr, part)
+                        : launch<true>(MT, true, grid, lds, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, (f16 *)y,
+                                       y_stride, nullptr, part);
     if (rc) return rc;
     const int64_t total = (int64_t)B * M_out / 4;
     hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, M_out, s, part,
@@ -564,4 +667,4 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
     return (int)hipGetLastError();
 }
 
-extern "C" void skinny_gemm_select(int use_ring) { g_use_ring = use_ring != 0; }
+extern "C" void skinny_gemm_select(int mode) { g_mode = mode < 0 || mode > 3 ? 3 : mode; }

@@ -166,6 +166,7 @@ class RWKV_x070:
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
+        self.skinny_ffn_key = False                      # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -423,8 +424,11 @@ class RWKV_x070:
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1)
                 delta = ops.mm8t_linear(kf, *lw.f_V8).view(B, T, C)
             else:
-                kf = F.linear(kin[0], lw.f_K)
-                ops.relu_sq_(kf)
+                if use_parts and self.skinny_ffn_key:
+                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K, act=1, splits=2)
+                else:
+                    kf = F.linear(kin[0], lw.f_K)
+                    ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
                 elif use_parts:

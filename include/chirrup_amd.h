@@ -166,8 +166,9 @@ int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
  * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
 int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
                             float *partials, void *stream);
-/* 1 (default): both operands through a 3-deep LDS-DMA ring; 0: register-staged variant. (A/B switch.) */
-void skinny_gemm_select(int use_ring);
+/* Kernel variant (A/B switch): 0 register-staged; 1 (default) both operands through one LDS-DMA ring;
+ * 2, 3: per-wave loader roles (x and W in separate rings, see skinny_gemm.hip). */
+void skinny_gemm_select(int mode);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
                     void *Y, int ldy, int act, int splits, void *workspace, void *stream);
 

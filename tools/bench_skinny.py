@@ -4,6 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 from chirrup_amd import ops
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+if len(sys.argv) > 2:
+    from chirrup_amd import lib
+    lib.load().skinny_gemm_select(int(sys.argv[2]))      # kernel variant, see include/chirrup_amd.h
+    print("kernel mode", sys.argv[2], flush=True)
 dev = "cuda:0"
 torch.manual_seed(0)
 def timeit(fn, iters=20):
