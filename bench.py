@@ -43,6 +43,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
+    p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=4, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
@@ -209,6 +210,8 @@ def main():
         lib.load().skinny_gemm_select(a.gemm_mode)
     if a.skinny_key is not None:
         model.skinny_ffn_key = bool(a.skinny_key)
+    if a.skinny_rkv is not None:
+        model.skinny_rkv = bool(a.skinny_rkv)
     state = make_state(model, B)
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)

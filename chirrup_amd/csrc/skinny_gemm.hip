@@ -66,13 +66,20 @@ struct WRaw {
 // Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
 // own L2: give XCD j a contiguous run of the K-slice-major tile order, so the x K-slice a workgroup re-reads is shared
 // by its L2 neighbours (ffn.value at bsz 200: x is 6.5 MB, a K-slice 0.8 MB; the L2 is 4 MB).
-__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice) {
-    const int G = gridDim.x, total = G * gridDim.y;
-    const int L = blockIdx.x + G * blockIdx.y;
-    const int v = (total & 7) ? L : (L & 7) * (total >> 3) + (L >> 3);
+__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch) {
+    const int G = gridDim.x, GS = G * gridDim.y, total = GS * gridDim.z;
+    const int L = blockIdx.x + G * blockIdx.y + GS * blockIdx.z;
+    int v = (total & 7) ? L : (L & 7) * (total >> 3) + (L >> 3);
+    batch = v / GS;
+    v -= batch * GS;
     kslice = v / G;
     ngroup = v - kslice * G;
 }
+
+// element strides between the problems of a batched launch (gridDim.z problems; 0s for a single GEMM)
+struct BatchStrides {
+    int64_t x, w, y, bias;
+};
 
 template <int MT, bool W8, int EPI>
 __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
@@ -83,8 +90,8 @@ __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
     constexpr int kTileBytes = MT * 32 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    int ngroup, kslice;
-    tile_of_block(ngroup, kslice);
+    int ngroup, kslice, batch_unused;
+    tile_of_block(ngroup, kslice, batch_unused);
     const int n0 = (ngroup * 4 + wave) * 32;
     const bool wave_live = n0 < N;
     const int k_begin = kslice * k_slice;
@@ -248,7 +255,7 @@ template <int MT, bool W8, int EPI, int XD, int WD, int RM>
 __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
     const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
-    const f16 *__restrict__ bias, float *__restrict__ part) {
+    const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs) {
     static_assert(RM == 1 || XD == WD, "one ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kXBytes = MT * 32 * 128;            // x K-block image
@@ -262,8 +269,13 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
     const bool computes = wave < 4;
     const bool loads_x = RM == 0 || (RM == 1 ? wave < 2 : wave >= 4), loads_w = RM == 0 || (RM == 1 ? wave >= 2 : wave >= 4);
     const int lt = RM == 1 ? (tid & 127) : (tid & 255), lw = RM == 1 ? (wave & 1) : (wave & 3);
-    int ngroup, kslice;
-    tile_of_block(ngroup, kslice);
+    int ngroup, kslice, batch;
+    tile_of_block(ngroup, kslice, batch);
+    X += batch * bs.x;
+    Wv = static_cast<const unsigned char *>(Wv) + batch * bs.w * (W8 ? 1 : 2);
+    if (Y) Y += batch * bs.y;
+    if (bias) bias += batch * bs.bias;
+    if (part) part += (int64_t)batch * gridDim.y * M * N;
     const int n_base = ngroup * kBN;
     const int n0 = n_base + wave * 32;
     const bool wave_live = computes && n0 < N;
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
 
 #ifndef SKINNY_EXP
 #define SKINNY_EXP 0   // ingest experiments (tools/exp_skinny_ingest.py): 1/2 = W / x always from the slice's first K-block,
-#endif                 // 4 = no MFMA, 8 = one x fragment per step
+#endif                 // 4 = fragments fetched but no MFMA
     auto stage_x = [&](int kb) {
         const int k0 = k_begin + ((SKINNY_EXP & 2) ? 0 : kb * kKB);
         unsigned char *base = xring + (kb % XD) * kXBytes;
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
             for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + wr * 128 + (((4 * h + s) ^ ((wr >> 1) & 7)) << 4));
         }
         auto bfrag = [&](int s, int mt) {
-            const int m = ((SKINNY_EXP & 8) ? 0 : mt * 32) + r;   // exp 8: one x fragment per step, reused (7x fewer LDS reads)
+            const int m = mt * 32 + r;
             return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
         };
 #if SKINNY_EXP & 4
@@ -417,14 +429,22 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
 //   mode 0: y = sum (+ bias[n]);  mode 1: y = relu(sum (+bias))^2;
 //   mode 2 (mm8): y = rx[n]*(sum + 0.5*S[m][0]) + S[m][1] + mx[n]*S[m][2]      (benchmark.py:167-179)
 //   mode 3: mm8 then relu^2
+//   mode 4 + p: the RWKV-7 LoRA hidden planes (v, w, a, g), first problem = plane p: tanh on w, sigmoid on g
+//               (rwkv7.py:626, :630), applied to the binary16-rounded sum like the reference's separate op
+// blockIdx.y = problem of a batched launch (partials [Z][splits][M][N], Y / bias advance by y_bs / bias_bs).
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const int N, const int splits,
                                                             const float *__restrict__ part, const f16 *__restrict__ bias,
                                                             const f16 *__restrict__ rx, const f16 *__restrict__ mx,
                                                             const float *__restrict__ S, const int mode,
-                                                            f16 *__restrict__ Y, const int ldy) {
+                                                            f16 *__restrict__ Y, const int ldy, const int64_t y_bs = 0,
+                                                            const int64_t bias_bs = 0) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = (int64_t)M * N / 4;
     if (gi >= total) return;
+    const int z = blockIdx.y;
+    part += (int64_t)z * splits * M * N;
+    Y += z * y_bs;
+    if (bias) bias += z * bias_bs;
     const int m = (int)(gi / (N / 4)), n = (int)(gi % (N / 4)) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N + n);
@@ -432,11 +452,16 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const i
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         float v = s[e];
-        if (mode >= 2) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
+        if (mode == 2 || mode == 3) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
         else if (bias) v += (float)bias[n + e];
         if (mode == 1 || mode == 3) {
             v = (float)(f16)v;                       // relu(fp16(y))**2, rwkv7.py:678
             v = v > 0.f ? v * v : 0.f;
+        } else if (mode >= 4) {
+            const int plane = z + mode - 4;
+            v = (float)(f16)v;
+            if (plane == 1) v = tanhf(v);
+            else if (plane == 3) v = 1.f / (1.f + __expf(-v));
         }
         o[e] = (f16)v;
     }
@@ -513,9 +538,9 @@ int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, i
 
 int g_mode = 3;             // 0: register-staged kernel; 1-3: LDS-DMA ring kernel variants (launch_ring_mode); 3 measured fastest
 
-int pick_splits(int N, int K, int requested) {
+int pick_splits(int N, int K, int requested, int Z = 1) {
     if (requested > 0) return requested;
-    const int ngroups = (N + kBN - 1) / kBN;
+    const int ngroups = Z * ((N + kBN - 1) / kBN);
     int s = (256 + ngroups - 1) / ngroups;             // aim at >= 256 workgroups
     const int max_s = K / 256 > 0 ? K / 256 : 1;       // keep >= 4 K-blocks per slice
     if (s > max_s) s = max_s;
@@ -529,7 +554,7 @@ int pick_splits(int N, int K, int requested) {
 // MODE 1: one ring, every wave loads both operands; 2: x / W loader roles, x 2 slots / W 6 (u8: 8); 3: dedicated loader waves
 template <bool W8, int EPI, int MODE>
 int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs) {
     constexpr int RM = MODE - 1;
     constexpr int XD = MODE == 2 ? 2 : (W8 ? 4 : 3);
     constexpr int WD = MODE == 2 ? (W8 ? 8 : 6) : XD;
@@ -539,7 +564,7 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
         auto kern = skinny_gemm_ring_kernel<MTV, W8, EPI, XD, WD, RM>;                                                    \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                   (int)lds);                                                                              \
-        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);     \
+        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs); \
     } while (0)
     switch (MT) {
         case 1: GO(1); break;
@@ -557,11 +582,11 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
 
 template <bool W8, int EPI>
 int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{0, 0, 0, 0}) {
     switch (g_mode) {
-        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
-        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
-        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part);
+        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
+        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
+        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
     }
 }
 
@@ -601,6 +626,45 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
         const int64_t total = (int64_t)M * N / 4;
         hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, s,
                            (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr, act ? 1 : 0, (f16 *)Y, ldy);
+        rc = (int)hipGetLastError();
+    }
+    return rc;
+}
+
+extern "C" int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int K, int splits) {
+    if (Z <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
+    return (int64_t)Z * pick_splits(N, K, splits, Z) * M * N * (int64_t)sizeof(float);
+}
+
+// Z independent problems in ONE launch: Y[z] = act(X[z] . W[z]^T + bias[z]); operands of problem z start z * (their
+// batch stride, in elements) after problem 0.  act: 0 none, 1 relu^2, 4 + p = LoRA hidden planes starting at plane p.
+extern "C" int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W,
+                                       int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy,
+                                       int64_t y_bs, int act, int splits, void *workspace, void *stream) {
+    if (Z <= 0 || Z > 65535 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N ||
+        (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
+        return CHIRRUP_E_SHAPE;
+    if (!X || !W || !Y) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
+        return CHIRRUP_E_ALIGN;
+    if (!g_mode) return CHIRRUP_E_UNSUPPORTED;            // the register-staged variant has no batch dimension
+    const int s = pick_splits(N, K, splits, Z);
+    const bool partial = s > 1 || act != 0;
+    if (partial && !workspace) return CHIRRUP_E_NULL;
+    const int MT = (M + 31) / 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((N + kBN - 1) / kBN, s, Z);
+    const BatchStrides bs{x_bs, w_bs, y_bs, bias_bs};
+    int rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                                                       (const f16 *)bias, (float *)workspace, bs)
+                     : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                                                   (const f16 *)bias, (float *)workspace, bs);
+    if (rc) return rc;
+    if (partial) {
+        const int64_t total = (int64_t)M * N / 4;
+        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), Z), dim3(256), 0, st, M, N, s,
+                           (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr, act, (f16 *)Y, ldy, y_bs,
+                           bias_bs);
         rc = (int)hipGetLastError();
     }
     return rc;

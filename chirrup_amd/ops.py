@@ -290,6 +290,34 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None)
     return out
 
 
+def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
+    """Batched skinny_linear in one launch: x [Z, M<=256, K], weight [Z, N, K] (K % 64 == 0), bias [Z, 1, N] or
+    [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA planes."""
+    if x.dim() != 3 or weight.dim() != 3 or x.shape[0] != weight.shape[0] or x.shape[2] != weight.shape[2]:
+        raise _lib.ChirrupAmdError("skinny_bmm: expected x [Z,M,K], weight [Z,N,K]")
+    for name, t in (("x", x), ("weight", weight)):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1:
+            raise _lib.ChirrupAmdError(f"{name}: expected GPU fp16 with unit inner stride")
+    Z, M, K = x.shape
+    N = weight.shape[1]
+    if out is None:
+        out = torch.empty((Z, M, N), dtype=torch.float16, device=x.device)
+    bias_bs = 0
+    if bias is not None:
+        bias = bias.view(Z, N)
+        if bias.dtype != torch.float16 or not bias.is_cuda or bias.stride(1) != 1:
+            raise _lib.ChirrupAmdError("bias: expected GPU fp16 [Z, N]")
+        bias_bs = bias.stride(0)
+    L = _lib.load()
+    nbytes = L.skinny_gemm_batched_workspace_bytes(Z, M, N, K, splits)
+    ws = _workspace(nbytes, x.device)
+    rc = L.skinny_gemm_f16_batched(Z, M, N, K, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), weight.stride(1),
+                                   weight.stride(0), _ptr(bias), bias_bs, out.data_ptr(), out.stride(1), out.stride(0), act,
+                                   splits, ws.data_ptr(), _stream())
+    _lib.check(rc, "skinny_gemm_f16_batched")
+    return out
+
+
 def skinny_linear_partial(x, weight, splits: int, partials):
     """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
     [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""

@@ -166,6 +166,7 @@ class RWKV_x070:
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
+        self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_ffn_key = False                      # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
@@ -392,7 +393,10 @@ class RWKV_x070:
                 hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
                 up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))         # + v0 / w0 / a0 / 0
-            rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))            # one launch for R, K, V
+            if use_parts and self.skinny_rkv:
+                rkv = ops.skinny_bmm(mixed[0:3].view(3, rows, C), lw.rkv, splits=2)          # one launch for R, K, V
+            else:
+                rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))
             if side is not None:
                 main.wait_stream(side)
                 hid.record_stream(main), up.record_stream(main)

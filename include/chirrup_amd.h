@@ -166,6 +166,15 @@ int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
  * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
 int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
                             float *partials, void *stream);
+/* Z independent skinny GEMMs in ONE launch (RWKV-7's receptance/key/value projections, Albatross/rwkv7.py:603-605,
+ * and its four LoRA pairs, :626-637): Y[z] = act(X[z] . W[z]^T + bias[z]).  Problem z's operands start z * (their
+ * batch stride, in elements) after problem 0's; bias may be NULL.  act: 0 none, 1 relu(.)^2, 4 + p: LoRA hidden
+ * planes (v, w, a, g) with problem 0 = plane p: tanh on w, sigmoid on g.  K must be a multiple of 64, M <= 256.
+ * Needs skinny_gemm_batched_workspace_bytes(...) bytes of scratch when splits != 1 or act != 0. */
+int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int K, int splits);
+int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W, int64_t ldw,
+                            int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs, int act,
+                            int splits, void *workspace, void *stream);
 /* Kernel variant (A/B switch): 0 register-staged; 1 (default) both operands through one LDS-DMA ring;
  * 2, 3: per-wave loader roles (x and W in separate rings, see skinny_gemm.hip). */
 void skinny_gemm_select(int mode);

@@ -77,3 +77,39 @@ def test_mm8t_matches_oracle(oracle, kernel_mode, B, N, M, splits, act):
     dense = x.astype(np.float32) @ w16.astype(np.float32)
     if not act:
         assert np.abs(got - dense).max() <= 0.05 * np.abs(dense).max()
+
+
+@pytest.mark.parametrize("Z,M,N,K,splits,bias,act", [
+    (3, 200, 4096, 4096, 2, False, 0), (3, 200, 4096, 4096, 0, False, 0), (4, 200, 512, 4096, 0, False, 4),
+    (3, 200, 512, 4096, 16, False, 5), (4, 200, 4096, 512, 1, True, 0), (4, 33, 256, 128, 2, True, 0), (2, 7, 132, 64, 1, True, 1)])
+def test_skinny_bmm_matches_fp64(Z, M, N, K, splits, bias, act):
+    """Batched launch (receptance/key/value and the LoRA pairs): every problem against fp64, incl. strided planes
+    of larger tensors and the fused LoRA activations (tanh on plane w, sigmoid on plane g)."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(Z * M + N + K)
+    xbig = torch.randn(Z + 1, M, K, device="cuda").half()
+    x = xbig[1:]                                               # planes of a larger tensor, like mixed[2:6]
+    w = (torch.randn(Z, N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(Z, 1, N, device="cuda").half() if bias else None
+    y = ops.skinny_bmm(x, w, b, act=act, splits=splits)
+    want = torch.bmm(x.double(), w.double().transpose(1, 2))
+    if b is not None:
+        want = want + b.double()
+    if act == 1:
+        want = torch.relu(want.half().double()) ** 2
+    elif act >= 4:
+        for z in range(Z):
+            plane = z + act - 4
+            if plane == 1:
+                want[z] = torch.tanh(want[z].half().double())
+            elif plane == 3:
+                want[z] = torch.sigmoid(want[z].half().double())
+    err = (y.double() - want).abs()
+    tol = (4e-3 if act == 1 else 2e-3) * want.abs().clamp_min(1.0)
+    assert bool((err <= tol).all()), float((err / want.abs().clamp_min(1.0)).max())
+    # the same problems one at a time give the same bits when the split count is the same
+    if act == 0 and splits > 0:
+        for z in range(Z):
+            y1 = ops.skinny_linear(x[z], w[z], None if b is None else b[z, 0], splits=splits)
+            assert torch.equal(y1, y[z])

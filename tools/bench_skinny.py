@@ -43,3 +43,21 @@ for name, N, K, splits_list in [("att CxC", 4096, 4096, (1, 2, 4, 8)), ("ffn.key
         print(line, flush=True)
         del Q
     del Ws
+# batched launches of the time-mix block (7.2B: C 4096, LoRA ranks padded to 512)
+for name, Z, N, K, splits_list, act in [("rkv 3xCxC", 3, 4096, 4096, (1, 2, 4), 0), ("lora dn x4", 4, 512, 4096, (4, 8, 16), 4),
+                                        ("lora up x4", 4, 4096, 512, (1, 2), 0)]:
+    nw = 8
+    Ws = [(torch.randn(Z, N, K, device=dev) / K ** 0.5).half() for _ in range(nw)]
+    x = torch.randn(Z, M, K, device=dev).half()
+    bias = torch.randn(Z, 1, N, device=dev).half()
+    if name.startswith("lora up"):
+        t0 = timeit(lambda: [torch.baddbmm(bias, x, W.transpose(1, 2)) for W in Ws]) / nw
+    else:
+        t0 = timeit(lambda: [torch.bmm(x, W.transpose(1, 2)) for W in Ws]) / nw
+    line = f"{name:12s} N={N:6d} K={K:6d}: torch {t0*1e3:7.1f} us |"
+    for s in splits_list:
+        b = bias if name.startswith("lora up") else None
+        t = timeit(lambda: [ops.skinny_bmm(x, W, b, act=act, splits=s) for W in Ws]) / nw
+        line += f" s{s}: {t*1e3:6.1f} us ({Z*N*K*2/t/1e6:5.0f} GB/s)"
+    print(line, flush=True)
+    del Ws
