@@ -363,7 +363,7 @@ class RWKV_x070:
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
         dparts = None                     # split-K partials of the previous ffn.value GEMM (summed by the next LN kernel)
-        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and 128 < rows <= 256
+        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and 64 < rows <= 256
                      and C >= self.skinny_min_embd)
         pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
 
