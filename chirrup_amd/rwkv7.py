@@ -536,23 +536,32 @@ class SlotDecodeGraph:
     request (its contents are garbage by design), so one captured graph serves any number of live rows
     up to ``B``; the worker keeps a few bucket sizes.  Inputs are written into static buffers."""
 
-    def __init__(self, model: RWKV_x070, pool, B: int, parking_slot: int, warmup: int = 2):
+    def __init__(self, model: RWKV_x070, pool, B: int, parking_slot: int, warmup: int = 2, feedback=None):
+        """feedback: optional int32 [n_slots] device vector; a row whose token is given as -1 takes
+        feedback[its slot] instead (the id sampled for that slot by the previous step, never seen by the host)."""
         assert model.fused, "needs the HIP path"
         self.model, self.pool, self.B, self.parking = model, pool, B, parking_slot
         dev = model.device
         self.tokens = torch.zeros((B, 1), dtype=torch.long, device=dev)
         self.slot_idx = torch.full((B,), parking_slot, dtype=torch.int32, device=dev)
+
+        def fwd():
+            tok = self.tokens
+            if feedback is not None:
+                tok = torch.where(tok < 0, feedback[self.slot_idx.long()].long().view(B, 1), tok)
+            return model.forward_slots(tok, pool, self.slot_idx)
+
         snap = [t.clone() for t in pool]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                model.forward_slots(self.tokens, pool, self.slot_idx)
+                fwd()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.logits = model.forward_slots(self.tokens, pool, self.slot_idx)
+            self.logits = fwd()
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):
             t.copy_(s_)

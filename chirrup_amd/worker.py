@@ -21,6 +21,14 @@ What is different is the DEVICE DISPATCH, redesigned for a 288 GB MI355X:
     real sampling parameters go through samplers.sample_logits_rwkv_pip_compatible.
   * prefix states exported for the cache stay in HBM by default (device clones; `state_cache_device="cpu"`
     restores the reference's host copies) -- a cache hit is then a 17-33 MB device-to-device copy.
+  * RUN-AHEAD: the sampled ids never have to reach the host before the next forward.  They are scattered into a
+    per-slot device vector (``last_ids``) that the next forward gathers its decode inputs from, and the penalty
+    state (occurrence += 1, presence) is updated on the device from the same ids.  ``step()`` therefore launches
+    forward k and only then reads and handles the ids of forward k-1 (text decode, stop / length checks, messages,
+    admission): the ~1 ms of per-token host bookkeeping runs under the ~9 ms forward instead of in series with it.
+    A request that turns out to have finished at k-1 has one speculative row in forward k; that row's result is
+    dropped (the slot is recycled afterwards, in stream order).  ``run_ahead=False`` handles each forward's ids in
+    the same ``step()`` call, like the reference's loop; both modes produce the same token streams.
 """
 import queue
 import time
@@ -67,13 +75,14 @@ def min_swaps_to_target_fast(lst, elements):
 
 def _empty_slot() -> dict:
     return {"task": None, "is_prefilling": None, "new_token": None, "next_input_token": None,
-            "state_category": StateCategory.EMPTY, "prefilled_tokens": [], "prefill_cached": False, "raw_logits": None}
+            "state_category": StateCategory.EMPTY, "prefilled_tokens": [], "prefill_cached": False,
+            "feedback": False}      # feedback: the slot's next decode input is last_ids[slot] on the device
 
 
 class Worker:
     def __init__(self, worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, task_queue: queue.Queue,
                  master_event_queue: queue.Queue, worker_event_queue: Optional[queue.Queue], batch_size: int = 32,
-                 model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None):
+                 model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None, run_ahead: bool = True):
         self.worker_id, self.gpu_id, self.model_config = worker_id, gpu_id, model_config
         self.task_queue, self.master_event_queue, self.worker_event_queue = task_queue, master_event_queue, worker_event_queue
         self.real_state_size = batch_size
@@ -88,6 +97,8 @@ class Worker:
         # 17-33 MB device-to-device copies instead of two PCIe transfers per cache hit); "cpu" = the
         # reference's behaviour (worker.py:427-429)
         self.state_cache_device = state_cache_device
+        self.run_ahead = run_ahead
+        self._inflight = None                         # the forward whose sampled ids the host has not handled yet
         self.no_penalty_token_ids = {33, 10, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58}
         self.min_forward_seq_len = 10
         self.max_forward_seq_len_per_forward = 100
@@ -136,6 +147,13 @@ class Worker:
         self.penalty_decay_tensor = torch.zeros((n, 1), dtype=torch.float16, device=dev)
         self.presence_penalty_tensor = torch.zeros((n, 1), **f32)
         self._greedy = [True] * n
+        # device-side feedback of the sampled ids (run-ahead): next decode inputs and the penalty bookkeeping
+        self.last_ids = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.penalty_weight = torch.ones((V,), **f32)           # occurrence increment per token id (worker.py:531)
+        self.penalty_weight[[t for t in self.no_penalty_token_ids if t < V]] = 0.0
+        self._ids_host = ([torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+                          if dev.type == "cuda" else None)
+        self._launches = 0
         # decode-step HIP graphs per batch bucket (captured lazily); slot n-1 is the parking slot
         self._graphs = {}
         self.use_graph = bool(getattr(self.model, "fused", False)) and self.device.type == "cuda"
@@ -196,35 +214,51 @@ class Worker:
             td["is_prefilling"], td["state_category"] = False, StateCategory.FORWARD_ONE_DECODE
         self._maybe_cache_prefill(td, slot)
 
-    def _handle_forward_one_decode_phase(self, td, slot: int):
+    def _handle_forward_one_decode_phase(self, td, tok: int, raw_logits=None):
+        """One sampled token of a live request (chirrup/worker.py:503-560): stop / length checks, text, message.
+        The penalty state was already advanced on the device when the token was sampled."""
         t: Task = td["task"]
-        tok = td["new_token"]
+        td["new_token"] = tok
         if tok in t.stop_tokens:
             t.request_status = RequestStatus.FINISHED_STOPPED
-            return None
+            return
         text = self.tokenizer.decode([tok], utf8_errors="ignore")
         t.generated_tokens.append(tok)
         t.decoded_texts.append(text)
-        if t.return_logits and td["raw_logits"] is not None:
-            t.output_queue.put_nowait(("token_generated", (tok, text, td["raw_logits"])))
-            td["raw_logits"] = None
+        if t.return_logits and raw_logits is not None:
+            t.output_queue.put_nowait(("token_generated", (tok, text, raw_logits.detach().cpu())))
         else:
             t.output_queue.put_nowait(("token_generated", (tok, text)))
         if len(t.generated_tokens) >= t.max_tokens:
             t.request_status = RequestStatus.FINISHED_LENGTH_CAPPED
-            return None
-        td["next_input_token"] = tok
-        return slot, tok, 0.0 if tok in self.no_penalty_token_ids else 1.0
-
-    def _batch_update_penalty(self, updates):
-        if not updates:
             return
-        dev = self.occurrence.device
-        slots = torch.tensor([u[0] for u in updates], device=dev, dtype=torch.long)
-        toks = torch.tensor([u[1] for u in updates], device=dev, dtype=torch.long)
-        wts = torch.tensor([u[2] for u in updates], device=dev, dtype=torch.float32)
-        self.occurrence[slots, toks] += wts
-        self.alpha_presence_vector[slots, toks] = self.presence_penalty_tensor[slots, 0]
+        td["next_input_token"] = tok
+
+    def _commit_sampled(self, ids: torch.Tensor, didx: torch.Tensor):
+        """Device-side consequences of sampling `ids` for the slots `didx`: the next decode input and the
+        repetition-penalty state (worker.py:527-535: occurrence += 1 except for the no-penalty ids, presence)."""
+        dl, il = didx.long(), ids.long()
+        self.last_ids.index_copy_(0, dl, ids)
+        self.occurrence.index_put_((dl, il), self.penalty_weight[il], accumulate=True)
+        self.alpha_presence_vector[dl, il] = self.presence_penalty_tensor[dl, 0]
+
+    def _handle_results(self, rec):
+        """Host half of a forward: read its sampled ids and run the per-token bookkeeping.  Rows whose request
+        is gone (finished or aborted while this forward was in flight) are dropped."""
+        if rec is None:
+            return
+        if rec["event"] is not None:
+            rec["event"].synchronize()
+        host_ids = rec["ids"][: len(rec["rows"])].tolist()        # ONE device->host copy for the whole batch
+        done = []
+        for j, (slot, task) in enumerate(rec["rows"]):
+            td = self.state_slot[slot]
+            if td["task"] is not task or RequestStatus.is_finished(task.request_status):
+                continue
+            self._handle_forward_one_decode_phase(td, int(host_ids[j]), rec["raw"].get(j))
+            if RequestStatus.is_finished(task.request_status):
+                done.append(slot)
+        self._process_accomplished_tasks(done)
 
     def _process_accomplished_tasks(self, slots):
         for s in slots:
@@ -289,9 +323,10 @@ class Worker:
         return torch.tensor(slots, dtype=torch.int32, device=self.device)
 
     def _run_forward_one(self, decode_slots: List[int], prefill_slots: List[int]):
+        """Enqueue one forward + sampling for these slots; returns the record `_handle_results` consumes."""
         slots = decode_slots + prefill_slots
         if not slots:
-            return
+            return None
         idx = self._slot_tensor(slots)
         nd = len(decode_slots)
         # every small host->device tensor is created BEFORE the forward is enqueued: a pageable H2D copy is
@@ -301,20 +336,29 @@ class Worker:
         if sampled:
             rows = torch.tensor(sampled, device=self.device, dtype=torch.int32)
             u = torch.rand((len(sampled),), device=self.device, dtype=torch.float32)
+        tokens = []
+        for j, s in enumerate(slots):
+            td = self.state_slot[s]
+            tokens.append(-1 if (j < nd and td["feedback"]) else td["next_input_token"])    # -1: last_ids[slot]
+            if j < nd:
+                td["feedback"] = True
         if self.use_graph:
-            out = self._graph_for(len(slots)).run([self.state_slot[s]["next_input_token"] for s in slots], slots)
+            out = self._graph_for(len(slots)).run(tokens, slots)
         else:
-            tokens = [[self.state_slot[s]["next_input_token"]] for s in slots]
-            out = self.model.forward_slots(tokens, self.batch_state, idx)
+            tok = torch.tensor(tokens, dtype=torch.long, device=self.device).view(-1, 1)
+            tok = torch.where(tok < 0, self.last_ids[idx.long()].long().view(-1, 1), tok)
+            out = self.model.forward_slots(tok, self.batch_state, idx)
+        self._launches += 1
         if nd == 0:
-            return
+            return None
         logits = out[:nd]
+        raw = {}
         for j, s in enumerate(decode_slots):
             t: Task = self.state_slot[s]["task"]
             if t.return_logits:
-                self.state_slot[s]["raw_logits"] = logits[j].clone().detach().cpu()
-            for tok in t.forbidden_tokens:
-                logits[j, tok] -= 1e10
+                raw[j] = logits[j].clone()
+            for tok_id in t.forbidden_tokens:
+                logits[j, tok_id] -= 1e10
         didx = idx[:nd]
         # penalties for every decode row + arg-max, one kernel; occurrence is decayed in place
         ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
@@ -329,9 +373,15 @@ class Worker:
                 srows = didx.long()[lrows]
                 ids[lrows] = sample_logits_rwkv_pip_compatible(logits[lrows], self.temperature_tensor[srows],
                                                                self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
-        host_ids = ids.tolist()                  # ONE device->host copy for the whole batch
-        for j, s in enumerate(decode_slots):
-            self.state_slot[s]["new_token"] = int(host_ids[j])
+        self._commit_sampled(ids, didx)
+        event = None
+        if self._ids_host is not None:
+            host = self._ids_host[self._launches & 1]
+            host[:nd].copy_(ids, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+            ids = host
+        return {"rows": [(s, self.state_slot[s]["task"]) for s in decode_slots], "ids": ids, "event": event, "raw": raw}
 
     def _graph_for(self, n: int):
         """Smallest captured bucket >= n (buckets: powers of two up to the slot count)."""
@@ -343,7 +393,8 @@ class Worker:
         b = min(b, self.max_batch_size)
         g = self._graphs.get(b)
         if g is None:
-            g = self._graphs[b] = SlotDecodeGraph(self.model, self.batch_state, b, parking_slot=self.real_state_size - 1)
+            g = self._graphs[b] = SlotDecodeGraph(self.model, self.batch_state, b, parking_slot=self.real_state_size - 1,
+                                                  feedback=self.last_ids)
         return g
 
     def _run_forward_seq(self, seq_slots: List[int]):
@@ -364,9 +415,12 @@ class Worker:
 
     # ------------------------------------------------------------------ main loop
     def step(self) -> bool:
-        """One loop iteration (chirrup/worker.py:793-884).  Returns False when idle."""
+        """One loop iteration (chirrup/worker.py:793-884).  Returns False when idle.
+        Order: (1) host-only slot bookkeeping that needs no sampled token (aborts, prompt cursors, admission),
+        (2) enqueue this iteration's forward(s), (3) handle sampled ids -- those of the PREVIOUS iteration's
+        forward when running ahead, else this one's."""
         t0 = time.perf_counter()
-        done, updates = [], []
+        done = []
         for slot in range(self.max_batch_size):
             td = self.state_slot[slot]
             cat = td["state_category"]
@@ -380,28 +434,31 @@ class Worker:
                 self._handle_forward_seq(td, slot)
             elif cat == StateCategory.FORWARD_ONE_PREFILL:
                 self._handle_forward_one_prefill_phase(td, slot)
-            elif cat == StateCategory.FORWARD_ONE_DECODE and td["new_token"] is not None:
-                upd = self._handle_forward_one_decode_phase(td, slot)
-                if upd is not None:
-                    updates.append(upd)
             if RequestStatus.is_finished(td["task"].request_status):
                 done.append(slot)
-        self._batch_update_penalty(updates)
         self._process_accomplished_tasks(done)
         self._fill_task_pool()
         cats = self._organize_batch()
         dec, pre, seq = (cats[c] for c in (StateCategory.FORWARD_ONE_DECODE, StateCategory.FORWARD_ONE_PREFILL,
                                            StateCategory.FORWARD_SEQ))
         if not dec and not pre and not seq:
-            return False
+            if self._inflight is None:
+                return False
+            rec, self._inflight = self._inflight, None           # drain the pipeline
+            self._handle_results(rec)
+            return True
+        rec = None
         if dec or pre:
-            self._run_forward_one(dec, pre)
+            rec = self._run_forward_one(dec, pre)
             self.seq_forward_count_down -= 1
         else:
             self.seq_forward_count_down = 0
         if self.seq_forward_count_down < 1 and seq:
             self._run_forward_seq(seq)
             self.seq_forward_count_down = max(1, self.decode_prefill_ratio)
+        if self.run_ahead:
+            rec, self._inflight = self._inflight, rec
+        self._handle_results(rec)
         self.iterations += 1
         self.loop_time_recorder.append(time.perf_counter() - t0)
         self._post({"avg_loop_time": sum(self.loop_time_recorder) / len(self.loop_time_recorder),

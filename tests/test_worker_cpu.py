@@ -95,11 +95,22 @@ class Sink:
         self.items.append(x)
 
 
+RUN_AHEAD = True
+
+
+@pytest.fixture(autouse=True, params=[True, False], ids=["run_ahead", "in_step"])
+def _both_scheduling_modes(request):
+    """Every worker test runs with the ids handled one forward behind (run-ahead) and in the same step."""
+    global RUN_AHEAD
+    RUN_AHEAD = request.param
+    yield
+
+
 def make_worker(batch_size=6):
     cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
     tq, mq, wq = queue.Queue(), queue.Queue(), queue.Queue()
     w = Worker("w0", [], cfg, tq, mq, wq, batch_size=batch_size, model=FakeModel(), tokenizer=FakeTok(),
-               penalize_argmax=cpu_penalize_argmax)
+               penalize_argmax=cpu_penalize_argmax, run_ahead=RUN_AHEAD)
     w._init_worker()
     return w, tq, mq, wq
 

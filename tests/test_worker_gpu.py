@@ -108,7 +108,8 @@ class _Sink:
         self.items.append(x)
 
 
-def test_worker_end_to_end_matches_unbatched_greedy():
+@pytest.mark.parametrize("run_ahead", [True, False], ids=["run_ahead", "in_step"])
+def test_worker_end_to_end_matches_unbatched_greedy(run_ahead):
     """Requests with short / medium / long prompts through the continuous-batching worker (slot pool,
     fused sampler, chunked prefill) produce exactly the ids of decoding each request alone.
     The two golden prompts (top-2 margin >= 0.03 at every step) also match the REFERENCE's ids."""
@@ -135,7 +136,7 @@ def test_worker_end_to_end_matches_unbatched_greedy():
 
     cfg = ModelLoadConfig(model_path="unused", vocab_path="unused", vocab_size=320, head_size=64)
     tq, mq = queue.Queue(), queue.Queue()
-    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=5, model=m, tokenizer=_Tok())
+    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=5, model=m, tokenizer=_Tok(), run_ahead=run_ahead)
     w._init_worker()
     tasks = []
     for p in prompts:
