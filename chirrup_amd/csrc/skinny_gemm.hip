@@ -690,6 +690,7 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
 // workspace layout: xs [B][N_in] f16 | S [B][3] f32 | partials [splits][B][M_out] f32
 extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) {
     if (B <= 0 || N_in <= 0 || M_out <= 0) return 0;
+    if (B > 256) B = 256;                                  // more rows are processed 256 at a time
     const int s = pick_splits(M_out, N_in, splits);
     int64_t b = (int64_t)B * N_in * 2;
     b = (b + 255) / 256 * 256;
@@ -701,7 +702,7 @@ extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) 
 extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,
                         const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
                         int splits, void *workspace, void *stream) {
-    if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
+    if (B <= 0 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
         y_stride < M_out || (x_stride & 7) || (w_stride & 15) || (y_stride & 3))
         return CHIRRUP_E_SHAPE;
     if (!x || !wT || !mx || !rx || !my || !ry || !y || !workspace) return CHIRRUP_E_NULL;
@@ -709,26 +710,37 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         return CHIRRUP_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int s = pick_splits(M_out, N_in, splits);
+    const int Bmax = B < 256 ? B : 256;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     f16 *xs = reinterpret_cast<f16 *>(ws);
-    int64_t off = ((int64_t)B * N_in * 2 + 255) / 256 * 256;
+    int64_t off = ((int64_t)Bmax * N_in * 2 + 255) / 256 * 256;
     float *S = reinterpret_cast<float *>(ws + off);
-    off += 256 * ((B * 3 * 4 + 255) / 256);
+    off += 256 * ((Bmax * 3 * 4 + 255) / 256);
     float *part = reinterpret_cast<float *>(ws + off);
-    hipLaunchKernelGGL(mm8_prep_kernel, dim3(B), dim3(256), 0, st, N_in, (const f16 *)x, x_stride, (const f16 *)ry,
-                       (const f16 *)my, xs, S);
-    const int MT = (B + 31) / 32;
-    const dim3 grid((M_out + kBN - 1) / kBN, s);
-    const size_t lds = (size_t)2 * MT * 32 * 128;
-    int rc = g_mode ? launch_ring<true, EPI_PARTIAL>(MT, grid, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride,
-                                                         (f16 *)y, y_stride, nullptr, part)
-                        : launch<true>(MT, true, grid, lds, st, B, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, (f16 *)y,
-                                       y_stride, nullptr, part);
-    if (rc) return rc;
-    const int64_t total = (int64_t)B * M_out / 4;
-    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, M_out, s, part,
-                       nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2, (f16 *)y, y_stride);
-    return (int)hipGetLastError();
+    // The kernel holds at most 256 activation rows per weight pass (8 accumulator tiles per wave): a longer batch
+    // (chunked prefill) is cut into 256-row blocks that re-stream the weights; the blocks reuse the workspace in
+    // stream order.
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int bn = (B - b0) < 256 ? (B - b0) : 256;
+        const f16 *xb = static_cast<const f16 *>(x) + (int64_t)b0 * x_stride;
+        f16 *yb = static_cast<f16 *>(y) + (int64_t)b0 * y_stride;
+        hipLaunchKernelGGL(mm8_prep_kernel, dim3(bn), dim3(256), 0, st, N_in, xb, x_stride, (const f16 *)ry, (const f16 *)my,
+                           xs, S);
+        const int MT = (bn + 31) / 32;
+        const dim3 grid((M_out + kBN - 1) / kBN, s);
+        const size_t lds = (size_t)2 * MT * 32 * 128;
+        int rc = g_mode ? launch_ring<true, EPI_PARTIAL>(MT, grid, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb,
+                                                         y_stride, nullptr, part)
+                        : launch<true>(MT, true, grid, lds, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb, y_stride,
+                                       nullptr, part);
+        if (rc) return rc;
+        const int64_t total = (int64_t)bn * M_out / 4;
+        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bn, M_out, s, part,
+                           nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2, yb, y_stride);
+        rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" void skinny_gemm_select(int mode) { g_mode = mode < 0 || mode > 3 ? 3 : mode; }

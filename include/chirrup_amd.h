@@ -175,8 +175,8 @@ int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int K, int spli
 int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W, int64_t ldw,
                             int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs, int act,
                             int splits, void *workspace, void *stream);
-/* Kernel variant (A/B switch): 0 register-staged; 1 (default) both operands through one LDS-DMA ring;
- * 2, 3: per-wave loader roles (x and W in separate rings, see skinny_gemm.hip). */
+/* Kernel variant (A/B switch): 0 register-staged; 1 both operands through one LDS-DMA ring loaded by the compute
+ * waves; 2 per-wave x / W loader roles; 3 (default) four dedicated loader waves (see skinny_gemm.hip). */
 void skinny_gemm_select(int mode);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
                     void *Y, int ldy, int act, int splits, void *workspace, void *stream);
@@ -187,7 +187,8 @@ int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, 
  * are static, the transpose is done once at load).  Evaluated in the reference's algebraically split
  * form (scripts/test_mm8/benchmark.py:167-179): xs = fp16(x*ry) through MFMA against the exact
  * uint8->binary16 weights, then y = rx*(acc + 0.5*sum xs) + sum x*my + mx*sum x.  act as above.
- * Replaces the tiled / WMMA variants scripts/test_mm8/rwkv_pip_operators.cu:205-558 (B <= 256).
+ * Replaces the tiled / WMMA variants scripts/test_mm8/rwkv_pip_operators.cu:205-558.  Any B: more than 256
+ * rows (chunked prefill) are processed 256 at a time, each block re-streaming the weights.
  */
 int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits);
 int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,

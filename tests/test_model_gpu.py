@@ -159,6 +159,15 @@ def test_mm8_channel_mix_model_vs_oracle(oracle):
         assert rel_linf(st8[1].cpu().numpy(), st_np[1]) <= 2e-3
         q_err = rel_linf(lg8.cpu().numpy(), lg16.cpu().numpy())
         assert 1e-4 < q_err < 0.08, q_err
+    # a prefill chunk with more than 256 rows (3 x 100 tokens): the mm8 GEMM runs in 256-row blocks
+    rng = np.random.default_rng(11)
+    toks = rng.integers(1, 320, (3, 100)).tolist()
+    st_np = [np.zeros_like(d[f"b3t1:{n}_in"]) for n in ("s0", "s1", "s2")]
+    lg_np = M.forward_seq_batch(z_np, toks, st_np, 2, mm8=mm8)
+    st8 = m8.generate_zero_state(3)
+    lg8 = m8.forward_seq_batch_seperate(toks, st8)
+    assert rel_linf(lg8.cpu().numpy(), lg_np) <= 6e-3
+    assert rel_linf(st8[1].cpu().numpy(), st_np[1]) <= 4e-3
 
 
 def test_bsz1_sparse_channel_mix_path(oracle):

@@ -52,7 +52,8 @@ def test_skinny_linear_matches_fp64(kernel_mode, M, N, K, splits, bias, act):
 
 
 @pytest.mark.parametrize("B,N,M,splits,act", [(4, 256, 512, 1, 0), (3, 512, 128, 2, 0), (200, 4096, 1024, 0, 0),
-                                              (200, 1024, 4096, 0, 1), (33, 320, 700 // 4 * 4, 1, 0)])
+                                              (200, 1024, 4096, 0, 1), (33, 320, 700 // 4 * 4, 1, 0),
+                                              (600, 512, 256, 0, 1)])       # > 256 rows: 256-row blocks (prefill chunks)
 def test_mm8t_matches_oracle(oracle, kernel_mode, B, N, M, splits, act):
     """MFMA mm8 vs the as-coded oracle.  The split form rounds xs = x*ry to fp16 once (the reference's
     own Albatross decomposition does the same, benchmark.py:167), so the bar is the reference's stated
