@@ -1,0 +1,250 @@
+"""Prefix-state cache (reference: chirrup/utils/state_cache.py:51-215).
+
+Two parts:
+
+* ``SimpleStateCache`` -- the reference's interface and observable behaviour (``check``, ``cache``, ``remove``,
+  ``check_and_wait_prefill``, ``awake_hang_up_prefills``; LRU over at most ``max_size`` prefixes, a prefix only
+  counts as a hit when at least one prompt token is left to feed, a lookup refreshes the entry's recency, caching
+  an already cached prefix keeps the first state).  It is checked operation by operation against traces of the
+  reference (tests/golden/state_cache.json).  Written as a reference-counted trie: every node counts the cached
+  prefixes that pass through it, and a branch disappears when its count reaches zero.
+  One deliberate difference: requests waiting for someone else's prefill are parked under the exact token
+  prefix they wait for, not on whichever trie node the lookup happened to stop at, so a waiter is always woken
+  by the ``cache()`` of that prefix (the reference can strand a waiter when the lookup walked past the last
+  cached prefix, state_cache.py:95-106).
+
+* ``HbmStateArena`` -- where the states live on an MI355X.  The reference keeps ``[L,2,1,C]``, ``[L,1,H,64,64]``,
+  ``[1]`` CPU tensors per entry (worker.py:426-430) and pays two PCIe transfers of 17-33 MB per hit.  With 288 GB
+  of HBM the cache is a preallocated, index-addressed pool on the device: ``capacity`` rows of
+  ``[L,2,C] + [L,H,64,64] + [1]``; caching a prefix is one device-to-device copy into a free row, a hit hands out
+  a device clone of the row (so an eviction can never pull a state from under a request that is still queued),
+  eviction just returns the row to the free list.  4096 rows of a 13.3B state (33 MB) are 135 GB.
+  ``SimpleStateCache(max_size, arena=HbmStateArena(...))`` stores its states there.
+"""
+import asyncio
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+
+class HbmStateArena:
+    """Preallocated pool of ``capacity`` RWKV-7 request states on one device."""
+
+    def __init__(self, n_layer: int, n_embd: int, capacity: int, device, head_size: int = 64, dtype=torch.float16):
+        if capacity <= 0:
+            raise ValueError("capacity must be positive")
+        self.n_layer, self.n_embd, self.capacity = n_layer, n_embd, capacity
+        H = n_embd // head_size
+        self.shift = torch.empty((capacity, n_layer, 2, n_embd), dtype=dtype, device=device)            # state[0] rows
+        self.wkv = torch.empty((capacity, n_layer, H, head_size, head_size), dtype=dtype, device=device)  # state[1] rows
+        self.elapsed = torch.zeros((capacity,), dtype=torch.int32, device=device)                       # state[2]
+        self._free = list(range(capacity - 1, -1, -1))
+
+    @classmethod
+    def for_model(cls, model, capacity: int):
+        """Geometry from a chirrup_amd.rwkv7.RWKV_x070 (n_layer, n_embd, head_size, device)."""
+        return cls(model.n_layer, model.n_embd, capacity, model.device, head_size=model.head_size)
+
+    @property
+    def bytes_per_state(self) -> int:
+        return (self.shift[0].numel() + self.wkv[0].numel()) * self.shift.element_size() + 4
+
+    @property
+    def free_rows(self) -> int:
+        return len(self._free)
+
+    def put(self, state: Sequence[torch.Tensor]) -> int:
+        """Copy one exported state ([L,2,1,C], [L,1,H,64,64], [1]; any device) into a free row; returns the row."""
+        if not self._free:
+            raise RuntimeError("HbmStateArena is full (the cache's max_size must not exceed the arena's capacity)")
+        s0, s1, s2 = state
+        if tuple(s0.shape) != (self.n_layer, 2, 1, self.n_embd) or s1.shape[0] != self.n_layer or s1.shape[1] != 1:
+            raise ValueError(f"state shapes {tuple(s0.shape)}, {tuple(s1.shape)} do not match the arena")
+        row = self._free.pop()
+        self.shift[row].copy_(s0[:, :, 0, :], non_blocking=True)
+        self.wkv[row].copy_(s1[:, 0], non_blocking=True)
+        self.elapsed[row: row + 1].copy_(s2.reshape(1), non_blocking=True)
+        return row
+
+    def get(self, row: int) -> List[torch.Tensor]:
+        """A device copy of row ``row`` in the layout ``Task.state`` / ``Worker._install`` expect."""
+        return [self.shift[row].unsqueeze(2).clone(), self.wkv[row].unsqueeze(1).clone(), self.elapsed[row: row + 1].clone()]
+
+    def release(self, row: int) -> None:
+        self._free.append(row)
+
+
+class _ArenaRow:
+    """What the LRU holds for an arena-backed entry."""
+    __slots__ = ("row",)
+
+    def __init__(self, row: int):
+        self.row = row
+
+
+class TrieNode:
+    """One token of a cached (or awaited) prefix.  ``entries`` = cached prefixes that pass through or end here."""
+    __slots__ = ("children", "state", "entries")
+
+    def __init__(self):
+        self.children: Dict[int, "TrieNode"] = {}
+        self.state = False
+        self.entries = 0
+
+    @property
+    def depend_count(self) -> int:          # the reference's name for the same counter
+        return self.entries
+
+
+class SimpleStateCache:
+    def __init__(self, max_size: int = 100, arena: Optional[HbmStateArena] = None):
+        if max_size <= 0:
+            raise ValueError("capacity must be positive")
+        if arena is not None and arena.capacity < max_size:
+            raise ValueError("the arena must have at least max_size rows")
+        self.max_size = max_size
+        self.arena = arena
+        self.root = TrieNode()
+        self._lru: "OrderedDict[Tuple[int, ...], object]" = OrderedDict()
+        self._waiting: Dict[Tuple[int, ...], asyncio.Condition] = {}     # prefixes somebody is prefilling right now
+        self.prefill_lock = asyncio.Lock()
+
+    # ------------------------------------------------------------------ bookkeeping
+    def __len__(self) -> int:
+        return len(self._lru)
+
+    def keys(self) -> List[Tuple[int, ...]]:
+        """Cached prefixes, least recently used first."""
+        return list(self._lru.keys())
+
+    def _materialise(self, stored):
+        if isinstance(stored, _ArenaRow):
+            return self.arena.get(stored.row)
+        return stored
+
+    def _drop_path(self, tokens: Tuple[int, ...]) -> None:
+        """Forget one cached prefix in the trie: decrement the counters along its path, cut the branch that only
+        this prefix kept alive."""
+        node = self.root
+        node.entries -= 1
+        for tok in tokens:
+            child = node.children[tok]
+            child.entries -= 1
+            if child.entries == 0:
+                del node.children[tok]
+                return
+            node = child
+        node.state = False
+
+    def _discard_state(self, stored) -> None:
+        if isinstance(stored, _ArenaRow):
+            self.arena.release(stored.row)
+        elif isinstance(stored, list):
+            del stored[:]                    # like the reference: the tensors are released now, not at GC time
+
+    # ------------------------------------------------------------------ the reference's interface
+    def check(self, tokens: List[int], return_trie_node: bool = False):
+        """Longest cached proper prefix of ``tokens`` -> (tokens still to feed, its state or None, its length
+        [, deepest trie node reached])."""
+        node, depth, hit = self.root, 0, 0
+        while depth < len(tokens):
+            if node.state:
+                hit = depth
+            nxt = node.children.get(tokens[depth])
+            if nxt is None or nxt.entries == 0:
+                break
+            node = nxt
+            depth += 1
+        key = tuple(tokens[:hit])
+        state = None
+        if key in self._lru:
+            self._lru.move_to_end(key)
+            state = self._materialise(self._lru[key])
+        if return_trie_node:
+            return tokens[hit:], state, hit, node
+        return tokens[hit:], state, hit
+
+    def cache(self, tokens: Tuple[int, ...], state: object, return_trie_node: bool = False):
+        """Remember ``state`` as the state after ``tokens``; evicts the least recently used prefix when full."""
+        tokens = tuple(tokens)
+        if not tokens:
+            return None
+        if tokens in self._lru:                    # already cached: refresh its recency, keep the first state
+            self._lru.move_to_end(tokens)
+            node = self.root
+            for tok in tokens:
+                node = node.children[tok]
+            return node if return_trie_node else None
+        node = self.root
+        node.entries += 1
+        for tok in tokens:
+            node = node.children.setdefault(tok, TrieNode())
+            node.entries += 1
+        node.state = True
+        self._lru[tokens] = _ArenaRow(self._put_after_eviction(state)) if self.arena is not None else state
+        if self.arena is None and len(self._lru) > self.max_size:
+            old_key, old_state = self._lru.popitem(last=False)
+            self._drop_path(old_key)
+            self._discard_state(old_state)
+        return node if return_trie_node else None
+
+    def _put_after_eviction(self, state) -> int:
+        """Arena-backed insert: make room first (the arena may be exactly max_size rows)."""
+        if len(self._lru) >= self.max_size:
+            old_key, old_state = self._lru.popitem(last=False)
+            self._drop_path(old_key)
+            self._discard_state(old_state)
+        return self.arena.put(state)
+
+    def remove(self, tokens: List[int]) -> None:
+        key = tuple(tokens)
+        if key not in self._lru:
+            return
+        stored = self._lru.pop(key)
+        self._drop_path(key)
+        self._discard_state(stored)
+
+    async def check_and_wait_prefill(self, tokens: List[int], cache_prefill_padding: int):
+        """Admission with de-duplicated prefills (state_cache.py:85-124): the first request for an uncached prompt
+        gets it back to prefill; identical requests arriving meanwhile wait and then start from the cached state."""
+        async with self.prefill_lock:
+            rest, state, hit = self.check(tokens)
+            if hit + cache_prefill_padding == len(tokens):
+                return rest, state, hit
+            wanted = tuple(tokens[:-cache_prefill_padding]) if cache_prefill_padding else tuple(tokens)
+            cond = self._waiting.get(wanted)
+            if cond is None:
+                self._waiting[wanted] = asyncio.Condition()
+                return rest, state, hit
+        async with cond:
+            await cond.wait()
+        if wanted in self._lru:
+            self._lru.move_to_end(wanted)
+            return list(tokens[len(wanted):]), self._materialise(self._lru[wanted]), len(wanted)
+        return rest, state, hit
+
+    async def awake_hang_up_prefills(self, node) -> bool:
+        """Wake the requests waiting for the prefix that ends at ``node`` (as returned by
+        ``cache(..., return_trie_node=True)``, or the prefix itself as a tuple of tokens)."""
+        key = node if isinstance(node, tuple) else self._prefix_of(node)
+        cond = self._waiting.pop(key, None) if key is not None else None
+        if cond is None:
+            return False
+        async with cond:
+            cond.notify_all()
+        return True
+
+    def _prefix_of(self, node: TrieNode) -> Optional[Tuple[int, ...]]:
+        for key in self._waiting:                   # few prefills are in flight at a time
+            walk = self.root
+            for tok in key:
+                walk = walk.children.get(tok)
+                if walk is None:
+                    break
+            if walk is node:
+                return key
+        return None
+
+
+__all__ = ["SimpleStateCache", "HbmStateArena", "TrieNode"]

@@ -105,6 +105,92 @@ def gen_sampler():
     npz("sampler.npz", **out)
 
 
+def gen_state_cache():
+    """Operation traces of the reference's prefix-state cache (chirrup/utils/state_cache.py:51-215): the trie +
+    LRU bookkeeping is pure Python, states are opaque labels here."""
+    import asyncio
+
+    from chirrup.utils.state_cache import SimpleStateCache
+
+    def lru_keys(c):
+        return [list(k) for k in c.LRU_cache.od.keys()]
+
+    traces = []
+    # (1) the scenario of the reference's own __main__ block (state_cache.py:218-235)
+    c = SimpleStateCache(max_size=3)
+    ops = []
+    for toks, label in (([1, 2, 3, 4], "state1"), ([1, 2, 3, 4, 5, 6, 7], "state1_2"), ([1, 2, 3, 6, 5, 6, 7, 8], "state2")):
+        c.cache(tuple(toks), label)
+        ops.append({"op": "cache", "tokens": toks, "state": label, "lru": lru_keys(c)})
+    for toks in ([1, 2, 3, 4], [1, 2, 3, 4, 5], [1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7, 8], [1, 2, 3, 6, 5],
+                 [1, 2, 3, 6, 5, 6, 7, 8, 9]):
+        rem, st, n = c.check(list(toks))
+        ops.append({"op": "check", "tokens": toks, "out": [rem, st, n], "lru": lru_keys(c)})
+    c.cache((1, 2, 3, 4, 5), "state1_3")
+    ops.append({"op": "cache", "tokens": [1, 2, 3, 4, 5], "state": "state1_3", "lru": lru_keys(c)})
+    rem, st, n = c.check([1, 2, 3, 4, 5])
+    ops.append({"op": "check", "tokens": [1, 2, 3, 4, 5], "out": [rem, st, n], "lru": lru_keys(c)})
+    traces.append({"max_size": 3, "ops": ops})
+    # (2) seeded random traces over a small alphabet: many shared prefixes, evictions, repeated keys, removes
+    rng = np.random.default_rng(77)
+    for max_size, n_ops, with_remove in ((2, 120, False), (4, 300, False), (7, 400, True), (3, 250, True)):
+        c = SimpleStateCache(max_size=max_size)
+        ops, serial = [], 0
+        for _ in range(n_ops):
+            toks = [int(t) for t in rng.integers(1, 4, size=int(rng.integers(1, 9)))]
+            kind = rng.random()
+            if kind < 0.45:
+                label = f"s{serial}"
+                serial += 1
+                c.cache(tuple(toks), label)
+                ops.append({"op": "cache", "tokens": toks, "state": label, "lru": lru_keys(c)})
+            elif kind < 0.9 or not with_remove:
+                rem, st, n = c.check(list(toks))
+                ops.append({"op": "check", "tokens": toks, "out": [rem, st, n], "lru": lru_keys(c)})
+            else:
+                keys = lru_keys(c)
+                if keys and rng.random() < 0.7:
+                    toks = keys[int(rng.integers(0, len(keys)))]
+                c.remove(list(toks))
+                ops.append({"op": "remove", "tokens": toks, "lru": lru_keys(c)})
+        traces.append({"max_size": max_size, "ops": ops})
+
+    # (3) the asynchronous admission path: two requests for the same uncached prompt (the second waits for the
+    # first one's prefill), then a full hit, then a wake-up without a cached state ("prefill failed")
+    async def scenario():
+        out = {}
+        c = SimpleStateCache(max_size=4)
+        prompt, pad = list(range(10, 22)), 2
+        out["first"] = list(await c.check_and_wait_prefill(list(prompt), pad))
+        waiter = asyncio.ensure_future(c.check_and_wait_prefill(list(prompt), pad))
+        await asyncio.sleep(0.01)
+        out["second_waits"] = not waiter.done()
+        node = c.cache(tuple(prompt[:-pad]), "P", return_trie_node=True)
+        out["awake"] = await c.awake_hang_up_prefills(node)
+        out["second"] = list(await asyncio.wait_for(waiter, 1.0))
+        out["third_full_hit"] = list(await c.check_and_wait_prefill(list(prompt), pad))
+        out["awake_again"] = await c.awake_hang_up_prefills(node)
+        other = list(range(40, 49))
+        out["other_first"] = list(await c.check_and_wait_prefill(list(other), pad))
+        waiter = asyncio.ensure_future(c.check_and_wait_prefill(list(other), pad))
+        await asyncio.sleep(0.01)
+        # the prefill is abandoned: wake the waiter up without caching anything
+        rem, st, n, node2 = c.check(other[:-pad] + [0], return_trie_node=True)
+        walk = c.root
+        for t in other[:-pad]:
+            walk = walk.children[t]
+        out["awake_failed"] = await c.awake_hang_up_prefills(walk)
+        out["other_second"] = list(await asyncio.wait_for(waiter, 1.0))
+        return {"prompt": prompt, "other": other, "padding": pad, "results": out}
+
+    asy = asyncio.run(scenario())
+    with open(os.path.join(HERE, "state_cache.json"), "w") as f:
+        json.dump({"source": "chirrup/utils/state_cache.py:51-215 SimpleStateCache (check / cache / remove / "
+                             "check_and_wait_prefill / awake_hang_up_prefills), states are labels",
+                   "traces": traces, "async": asy}, f)
+    print("wrote state_cache.json", sum(len(t["ops"]) for t in traces), "ops")
+
+
 def gen_tokenizer():
     from Albatross.utils import TRIE_TOKENIZER
 
@@ -308,6 +394,7 @@ if __name__ == "__main__":
     native.build()
     gen_scheduler()
     gen_sampler()
+    gen_state_cache()
     gen_tokenizer()
     gen_tokenizer_mini()
     gen_mm8()

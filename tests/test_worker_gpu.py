@@ -210,3 +210,49 @@ def test_sample_topp_distribution(V, temp, top_p, top_k):
         assert float((freq - q).abs().max()) <= 0.02
     if top_p == 0.0 or top_k == 1:
         assert bool((draws == int(p.argmax())).all())
+
+
+def test_prefix_cache_in_hbm_arena_round_trip():
+    """Row 8f-1 end to end: the worker exports a prefix state (device-resident), the arena-backed cache stores it
+    with one device-to-device copy, a later request with the same prefix starts from the arena's copy and
+    produces exactly the ids of the uncached request; evicting the entry does not disturb a state already
+    handed out."""
+    from chirrup_amd.core_structure import ModelLoadConfig, Task
+    from chirrup_amd.state_cache import HbmStateArena, SimpleStateCache
+    from chirrup_amd.worker import Worker
+
+    d, m = _tiny_model()
+    arena = HbmStateArena.for_model(m, capacity=2)
+    cache = SimpleStateCache(max_size=2, arena=arena)
+    cfg = ModelLoadConfig(model_path="unused", vocab_path="unused", vocab_size=320, head_size=64)
+    tq, mq = queue.Queue(), queue.Queue()
+    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=4, model=m, tokenizer=_Tok())
+    w._init_worker()
+    rng = np.random.default_rng(3)
+    prompt = rng.integers(1, 320, 40).tolist()
+
+    def run(task):
+        tq.put(task)
+        for _ in range(2000):
+            if not w.step():
+                break
+        return [x[1][0] for x in task.output_queue.items if x[0] == "token_generated"]
+
+    mk = lambda toks, state=None, **kw: Task(output_queue=_Sink(), task_event_queue=queue.Queue(), prompt_str="",
+                                             prefill_tokens=list(toks), state=state, temperature=0.0, frequency_penalty=0.0,
+                                             presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=8, **kw)
+    t1 = mk(prompt, cache_prefill=True, cache_prefill_padding=3)
+    ids1 = run(t1)
+    exported = [x[1] for x in t1.output_queue.items if x[0] == "cache_prefill"]
+    assert len(exported) == 1 and exported[0]["state"][1].is_cuda
+    seen = tuple(exported[0]["prefilled_tokens"])
+    cache.cache(seen, exported[0]["state"])
+    assert arena.free_rows == 1
+    rest, state, n = cache.check(list(prompt))
+    assert n == len(seen) and rest == prompt[n:] and state[0].is_cuda and tuple(state[1].shape) == (2, 1, 2, 64, 64)
+    assert torch.equal(state[1], exported[0]["state"][1]) and int(state[2][0]) == n
+    cache.cache((1, 2, 3), exported[0]["state"])
+    cache.cache((4, 5, 6), exported[0]["state"])            # evicts `seen`; `state` is a copy and stays valid
+    assert cache.check(list(prompt))[1] is None
+    ids2 = run(mk(rest, state=state))
+    assert ids2 == ids1 and len(ids1) == 8
