@@ -1,5 +1,10 @@
 """A/B of WKV7 kernel builds (tools/wkv7_variants/libwkv7_*.so): interleaved rounds in ONE process
-(cdna_hip_programming.md rule 24), graph replay of L back-to-back launches over L distinct layer states."""
+(cdna_hip_programming.md rule 24), graph replay of L back-to-back launches over L distinct layer states.
+Build the variants first (no GPU needed), e.g.
+  mkdir -p tools/wkv7_variants && for v in "base" "aux0 -DWKV7_LOAD_AUX=0" "st0 -DWKV7_NT_STORE=0"; do set -- $v; n=$1; shift;
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude "$@" -shared chirrup_amd/csrc/wkv7.hip \
+      -o tools/wkv7_variants/libwkv7_$n.so; done
+(results of the round-1 run: profiles/r01_wkv7_ab_cache_policy.txt)"""
 import ctypes, glob, os, sys, statistics as st
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
