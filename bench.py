@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
     p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
@@ -226,12 +227,28 @@ def main():
     from chirrup_amd import ops
 
     ids_dev = torch.empty((B,), dtype=torch.int32, device=dev)
-    ids_host = torch.empty((B,), dtype=torch.int32).pin_memory()
+    ids_host = [torch.full((B,), -1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    pending = [None, None]                           # event of the copy into ids_host[i]
+    n_steps = [0]
 
     def one_step(tok):
+        """Like Worker.step() with run-ahead: the sampled ids feed the next step on the device; the host receives
+        every step's ids through an asynchronous copy and consumes them one step behind."""
         logits = step_fn(tok)
         ops.penalize_argmax(logits, out=ids_dev)     # greedy (temperature 0, samplers.py:195-197), penalties 0
-        ids_host.copy_(ids_dev, non_blocking=False)  # the worker needs the ids on the host each step
+        i = n_steps[0] & 1
+        if a.sync_ids:
+            ids_host[i].copy_(ids_dev, non_blocking=False)
+        else:
+            ids_host[i].copy_(ids_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev = pending[i ^ 1]
+            if prev is not None:                     # the previous step's ids: on the host before this step ends
+                prev.synchronize()
+                assert int(ids_host[i ^ 1][0]) >= 0
+            pending[i] = ev
+        n_steps[0] += 1
         return ids_dev.view(B, 1)
 
     from chirrup_amd.dist_util import timed_region
@@ -270,7 +287,7 @@ def main():
             "dtype": "f16" if not a.mm8 else "f16 (u8 ffn weights, mm8)", "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
-                                   "greedy decode step incl. sampling and token-id D2H; random-init weights",
+                                   "greedy decode step incl. sampling and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "graph": not a.no_graph, "fused_elementwise": not a.no_fused},
             "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel<1> (fused time-mix core)" if fused_core else "wkv7_seq_kernel<0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
