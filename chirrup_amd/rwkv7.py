@@ -23,6 +23,7 @@ and the whole decode step can be captured in a HIP graph (`capture_decode_graph`
 the reference's eager semantics); that path exists for parity tests and for CPU host-logic tests
 and still calls the HIP WKV7 kernel on GPU -- there is no CPU fallback in the product.
 """
+import os
 import types
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -106,7 +107,7 @@ class _Layer:
         self.R, self.K, self.V = self.rkv[0], self.rkv[1], self.rkv[2]
         downs, ups = (self.v1, self.w1, self.a1, self.g1), (self.v2, self.w2, self.a2, self.g2)
         dmax = max(t.shape[0] for t in downs)
-        dmax = (dmax + 31) // 32 * 32
+        dmax = (dmax + 63) // 64 * 64              # whole 64-wide K-blocks for the MFMA kernels
         self.lora1 = torch.zeros((4, dmax, C), dtype=DTYPE, device=dev)
         self.lora2 = torch.zeros((4, C, dmax), dtype=DTYPE, device=dev)
         for j, (d_, u_, n) in enumerate(zip(downs, ups, "vwag")):
@@ -161,11 +162,13 @@ class RWKV_x070:
         self._layers = [_Layer(self.z, i) for i in range(self.n_layer)] if auto_load else []
         # the LoRA chain (2 small batched GEMMs + activation) is independent of the R/K/V GEMM: it runs
         # on a side stream, forked and joined with events (capturable in the decode graph)
+        # (a high-priority side stream was tried for the LoRA chain: the captured step went 8.4 -> 14.1 ms)
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
+        self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_ffn_key = False                      # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
@@ -392,7 +395,10 @@ class RWKV_x070:
             with torch.cuda.stream(side if side is not None else main):
                 hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
-                up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))         # + v0 / w0 / a0 / 0
+                if use_parts and self.skinny_lora_up and hid.shape[2] % 64 == 0:
+                    up = ops.skinny_bmm(hid, lw.lora2[p0:], lw.lbias[p0:], splits=1)            # bias in the epilogue
+                else:
+                    up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))     # + v0 / w0 / a0 / 0
             if use_parts and self.skinny_rkv:
                 rkv = ops.skinny_bmm(mixed[0:3].view(3, rows, C), lw.rkv, splits=2)          # one launch for R, K, V
             else:
