@@ -194,12 +194,25 @@ def main():
     local = local % max(1, torch.cuda.device_count())    # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    grouped = world > 1 or bool(os.environ.get("CHIRRUP_BENCH_FORCE_DIST"))   # the latter: 1-rank RCCL rehearsal
+    if grouped:
         backend = os.environ.get("CHIRRUP_BENCH_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm; gloo for rehearsals
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON
+        # line of the contract, so the banner is sent to stderr (file-descriptor level: it is written from C).
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from chirrup_amd.synth import CONFIGS
@@ -306,7 +319,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, B, a.cpu_layers)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

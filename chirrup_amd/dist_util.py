@@ -16,19 +16,19 @@ def shard_requests(n_requests: int, world: int, rank: int) -> List[int]:
 def timed_region(fn: Callable[[], None], steps: int, device: torch.device) -> float:
     """barrier -> sync -> `steps` calls -> sync -> barrier; returns the MAX over ranks of the
     elapsed seconds (the driver's bench contract)."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
+    grouped = dist.is_initialized()          # also with a single rank: the same calls run whenever a group exists
     sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
-    if world > 1:
+    if grouped:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     sync()
-    if world > 1:
+    if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         on_gpu = device.type == "cuda" and dist.get_backend() == "nccl"
         t = torch.tensor([dt], dtype=torch.float64, device=device if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
