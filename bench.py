@@ -46,7 +46,7 @@ def parse():
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
-    p.add_argument("--cpu-layers", type=int, default=8, help="layers of the model the CPU baseline times")
+    p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
 
