@@ -256,3 +256,64 @@ def test_prefix_cache_in_hbm_arena_round_trip():
     assert cache.check(list(prompt))[1] is None
     ids2 = run(mk(rest, state=state))
     assert ids2 == ids1 and len(ids1) == 8
+
+
+def test_worker_stress_protocol_consistency():
+    """Staggered arrivals, every prompt-length class, greedy and sampled rows, penalties, stop tokens, aborts and
+    prefix exports on a 0.1B synthetic model over 16 slots (run-ahead on): every request must see exactly one
+    task_completed, as its last message; tokens must match the task's own record and respect max_tokens; all slots
+    must be free at the end.  (tools/stress_worker.py is the larger form of this.)"""
+    import random
+
+    from chirrup_amd.core_structure import ModelLoadConfig, RequestStatus, Task
+    from chirrup_amd.rwkv7 import RWKV_x070, model_args
+    from chirrup_amd.synth import CONFIGS, make_state_dict
+    from chirrup_amd.worker import Worker
+
+    L, C = CONFIGS["0.1B"]
+    dev = torch.device("cuda", 0)
+    model = RWKV_x070(model_args("synthetic"), state_dict=make_state_dict(L, C, 65536, seed=3, device=dev), device=dev)
+    cfg = ModelLoadConfig(model_path="synthetic", vocab_path="none", vocab_size=65536, head_size=64)
+    tq, mq = queue.Queue(), queue.Queue()
+    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=17, model=model, tokenizer=_Tok())
+    w._init_worker()
+    rng = random.Random(11)
+    tasks, pending = [], []
+    for _ in range(120):
+        greedy = rng.random() < 0.5
+        t = Task(output_queue=_Sink(), task_event_queue=queue.Queue(), prompt_str="",
+                 prefill_tokens=[rng.randrange(1, 65536) for _ in range(rng.choice([1, 2, 9, 10, 11, 40, 100, 101, 230]))], state=None,
+                 temperature=0.0 if greedy else 1.0, top_p=0.0 if greedy else rng.choice([0.3, 0.9, 1.0]), top_k=rng.choice([0, 0, 20]),
+                 frequency_penalty=rng.choice([0.0, 0.5]), presence_penalty=rng.choice([0.0, 0.5]), penalty_decay=0.996,
+                 stop_tokens=[] if rng.random() < 0.7 else [rng.randrange(1, 65536) for _ in range(3000)], max_tokens=rng.randrange(1, 40),
+                 cache_prefill=rng.random() < 0.2, cache_prefill_padding=rng.choice([0, 1, 3]))
+        t._abort_at = rng.randrange(2, 60) if rng.random() < 0.1 else None
+        tasks.append(t)
+        pending.append(t)
+    it = 0
+    while True:
+        for _ in range(rng.randrange(0, 4)):
+            if pending:
+                tq.put(pending.pop())
+        for t in tasks:
+            if t._abort_at == it:
+                t.task_event_queue.put(("abort", None))
+        busy = w.step()
+        it += 1
+        if not busy and not pending:
+            break
+        assert it < 20000
+    outcomes = set()
+    for t in tasks:
+        kinds = [k for k, _ in t.output_queue.items]
+        assert kinds.count("task_completed") == 1 and kinds[-1] == "task_completed"
+        toks = [p[0] for k, p in t.output_queue.items if k == "token_generated"]
+        assert toks == t.generated_tokens and len(toks) <= t.max_tokens and all(0 <= x < 65536 for x in toks)
+        assert RequestStatus.is_finished(t.request_status)
+        if t.request_status == RequestStatus.FINISHED_LENGTH_CAPPED:
+            assert len(toks) == t.max_tokens
+        elif t.request_status == RequestStatus.FINISHED_STOPPED:
+            assert len(toks) < t.max_tokens
+        outcomes.add(t.request_status)
+    assert all(td["task"] is None for td in w.state_slot.values())
+    assert {RequestStatus.FINISHED_LENGTH_CAPPED, RequestStatus.FINISHED_ABORTED} <= outcomes
