@@ -95,6 +95,7 @@ class AsyncEngineCore:
                 w = self._make_worker(worker_id=wid, gpu_id=[k], model_config=model_config, task_queue=self.task_queue,
                                       master_event_queue=self.event_queue, worker_event_queue=self.worker_event_queue,
                                       batch_size=batch_size)
+                w.on_fatal = self._on_worker_fatal
                 self.workers.append(w)
                 t = threading.Thread(target=w.start, daemon=True, name=f"chirrup:{wid}")
                 t.start()
@@ -106,9 +107,9 @@ class AsyncEngineCore:
                 except asyncio.TimeoutError:
                     budget -= 1
                     continue
+                if kind == "worker_error" or (kind == "worker_loaded" and payload.get("status") != "success"):
+                    raise RuntimeError(f"Worker {wid} failed to load: {payload}")
                 if kind == "worker_loaded":
-                    if payload.get("status") != "success":
-                        raise RuntimeError(f"Worker {wid} failed to load: {payload}")
                     loaded.add(wid)
             if len(loaded) < worker_num:
                 raise RuntimeError(f"workers timed out while loading: {self.worker_id_set - loaded}")
@@ -140,6 +141,22 @@ class AsyncEngineCore:
                                      stop_tokens=stop_tokens, forbidden_tokens=forbidden_tokens, max_tokens=max_tokens,
                                      cache_prefill=cache_prefill, cache_prefill_padding=cache_prefill_padding,
                                      return_logits=return_logits)
+
+    def _on_worker_fatal(self, worker, exc) -> None:
+        """Called on a dying worker's thread.  When it was the last live worker, nobody will ever pick up the
+        requests still in the shared queue: complete them as aborted instead of leaving their clients waiting."""
+        me = threading.current_thread()
+        if any(t.is_alive() and t is not me for t in self.worker_threads):
+            return
+        from .core_structure import RequestStatus
+
+        while True:
+            try:
+                task = self.task_queue.get_nowait()
+            except Exception:                    # noqa: BLE001 -- queue.Empty
+                break
+            task.request_status = RequestStatus.FINISHED_ABORTED
+            task.output_queue.put_nowait(("task_completed", task))
 
     def shutdown(self) -> None:
         if self.is_shutdown:

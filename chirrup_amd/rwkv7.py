@@ -150,7 +150,7 @@ class RWKV_x070:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self.device = torch.device(device)
         if state_dict is None:
-            state_dict = torch.load(args.MODEL_NAME + ".pth", map_location="cpu")   # rwkv7.py:171
+            state_dict = torch.load(args.MODEL_NAME + ".pth", map_location="cpu", weights_only=True)   # rwkv7.py:171
         self.n_head, self.head_size = state_dict["blocks.0.att.r_k"].shape
         assert self.head_size == HEAD_SIZE == args.head_size
         args.n_embd = self.n_head * self.head_size

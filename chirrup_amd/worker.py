@@ -98,6 +98,7 @@ class Worker:
         # reference's behaviour (worker.py:427-429)
         self.state_cache_device = state_cache_device
         self.run_ahead = run_ahead
+        self.on_fatal = None                          # callable(worker, exception), set by the engine
         self._inflight = None                         # the forward whose sampled ids the host has not handled yet
         self.no_penalty_token_ids = {33, 10, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58}
         self.min_forward_seq_len = 10
@@ -222,7 +223,10 @@ class Worker:
         if tok in t.stop_tokens:
             t.request_status = RequestStatus.FINISHED_STOPPED
             return
-        text = self.tokenizer.decode([tok], utf8_errors="ignore")
+        try:
+            text = self.tokenizer.decode([tok], utf8_errors="ignore")
+        except KeyError:                 # an id the vocabulary file does not define (the model's vocab is padded)
+            text = ""
         t.generated_tokens.append(tok)
         t.decoded_texts.append(text)
         if t.return_logits and raw_logits is not None:
@@ -470,14 +474,39 @@ class Worker:
         return True
 
     def start(self):
-        if self.batch_state is None:
-            self._init_worker()
-        while True:
-            if self._process_events():
-                break
-            if not self.step():
-                time.sleep(0.05)
-        self._cleanup()
+        """The worker thread's entry point.  A failure anywhere in the loop must not strand the clients: it is
+        reported on the worker event queue and on stderr, and every request this worker holds is completed as
+        aborted before the thread ends (the reference's loop has no such path: a dead worker thread leaves its
+        requests waiting forever)."""
+        try:
+            if self.batch_state is None:
+                self._init_worker()
+            while True:
+                if self._process_events():
+                    break
+                if not self.step():
+                    time.sleep(0.05)
+        except BaseException as exc:             # noqa: BLE001 -- report, release the clients, then re-raise
+            import traceback
+
+            traceback.print_exc()
+            self._post({"status": "failed", "worker_id": self.worker_id, "error": repr(exc)}, "worker_error")
+            self._fail_all_requests()
+            if self.on_fatal is not None:
+                self.on_fatal(self, exc)         # the engine releases queued requests if no worker is left
+            raise
+        finally:
+            self._cleanup()
+
+    def _fail_all_requests(self):
+        for td in list(getattr(self, "state_slot", {}).values()):
+            t = td.get("task")
+            if t is not None and not RequestStatus.is_finished(t.request_status):
+                t.request_status = RequestStatus.FINISHED_ABORTED
+                try:
+                    t.output_queue.put_nowait(("task_completed", t))
+                except Exception:                # noqa: BLE001
+                    pass
 
     def _cleanup(self):
         for name in ("state_slot", "batch_state", "occurrence", "alpha_presence_vector", "model"):

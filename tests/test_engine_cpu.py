@@ -66,3 +66,28 @@ def test_engine_end_to_end():
             eng.completion("x")
 
     asyncio.run(main())
+
+
+@pytest.mark.filterwarnings("ignore::pytest.PytestUnhandledThreadExceptionWarning")
+def test_worker_failure_releases_every_client():
+    """A worker whose loop dies (here: the backend raises) must not leave clients waiting: requests in its slots
+    and, when it was the last worker, requests still queued are completed as aborted; a load failure fails init."""
+    class Boom(FakeModel):
+        def forward_slots(self, *a, **k):
+            raise RuntimeError("backend failure")
+
+    def factory(**kw):
+        return Worker(model=Boom(), tokenizer=_Tok(), penalize_argmax=cpu_penalize_argmax, **kw)
+
+    async def main():
+        eng = AsyncEngineCore(worker_factory=factory, tokenizer=_Tok())
+        cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
+        await eng.init(worker_num=1, model_config=cfg, batch_size=3)
+        kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=5)
+        cs = [eng.completion("", prefill_tokens=[1, 2, 3], **kw) for _ in range(6)]     # more than the slots
+        outs = await asyncio.wait_for(asyncio.gather(*[c.get_full_completion() for c in cs]), 10.0)
+        assert outs == [""] * 6
+        assert all(str(c.task.request_status) == "FINISHED_ABORTED" for c in cs)
+        eng.shutdown()
+
+    asyncio.run(main())
