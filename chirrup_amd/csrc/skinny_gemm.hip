@@ -79,6 +79,7 @@ __device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &bat
 // element strides between the problems of a batched launch (gridDim.z problems; 0s for a single GEMM)
 struct BatchStrides {
     int64_t x, w, y, bias;
+    int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
 };
 
 template <int MT, bool W8, int EPI>
@@ -280,8 +281,9 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
     const int n0 = n_base + wave * 32;
     const bool wave_live = computes && n0 < N;
     const int k_begin = kslice * k_slice;
-    const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
-    const int nkb = (k_end - k_begin) / kKB;
+    const int Kz = (batch < 8 && bs.k[batch] > 0) ? bs.k[batch] : K;
+    const int k_end = (k_begin + k_slice) < Kz ? (k_begin + k_slice) : Kz;
+    const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
     unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
 
     f32x16 acc[MT];
@@ -586,7 +588,7 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
 
 template <bool W8, int EPI>
 int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{0, 0, 0, 0}) {
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{}) {
     switch (g_mode) {
         case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
         case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
@@ -645,6 +647,17 @@ extern "C" int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int 
 extern "C" int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W,
                                        int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy,
                                        int64_t y_bs, int act, int splits, void *workspace, void *stream) {
+    return skinny_gemm_f16_grouped(Z, M, N, K, nullptr, X, ldx, x_bs, W, ldw, w_bs, bias, bias_bs, Y, ldy, y_bs, act, splits,
+                                   workspace, stream);
+}
+
+// As skinny_gemm_f16_batched, with a reduction length per problem: problem z multiplies only the first k_of[z] columns
+// of X[z] and W[z] (k_of[z] <= K, a multiple of 64; k_of == NULL: K for all).  For operands that are zero-padded to a
+// common K (RWKV-7's LoRA ranks: 96 / 128 / 128 / 480 packed as 512) the padding is then never read.  Z <= 8, and
+// splits must be 1 when k_of is given.
+extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs,
+                                       const void *W, int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y,
+                                       int ldy, int64_t y_bs, int act, int splits, void *workspace, void *stream) {
     if (Z <= 0 || Z > 65535 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N ||
         (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
         return CHIRRUP_E_SHAPE;
@@ -658,7 +671,15 @@ extern "C" int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X
     const int MT = (M + 31) / 32;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((N + kBN - 1) / kBN, s, Z);
-    const BatchStrides bs{x_bs, w_bs, y_bs, bias_bs};
+    BatchStrides bs{};
+    bs.x = x_bs, bs.w = w_bs, bs.y = y_bs, bs.bias = bias_bs;
+    if (k_of) {
+        if (Z > 8 || splits != 1) return CHIRRUP_E_UNSUPPORTED;
+        for (int z = 0; z < Z; z++) {
+            if (k_of[z] <= 0 || k_of[z] > K || (k_of[z] % kKB)) return CHIRRUP_E_SHAPE;
+            bs.k[z] = k_of[z];
+        }
+    }
     int rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                        (const f16 *)bias, (float *)workspace, bs)
                      : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,

@@ -15,6 +15,8 @@ Differences from the reference, all on the safe side:
 """
 from typing import Optional
 
+import ctypes
+
 import torch
 
 from . import lib as _lib
@@ -290,9 +292,11 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None)
     return out
 
 
-def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
+def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_of=None):
     """Batched skinny_linear in one launch: x [Z, M<=256, K], weight [Z, N, K] (K % 64 == 0), bias [Z, 1, N] or
-    [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA planes."""
+    [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA planes.
+    k_of: optional per-problem reduction lengths (multiples of 64, <= K; needs splits=1): zero-padded tails of
+    x / weight beyond k_of[z] are not read."""
     if x.dim() != 3 or weight.dim() != 3 or x.shape[0] != weight.shape[0] or x.shape[2] != weight.shape[2]:
         raise _lib.ChirrupAmdError("skinny_bmm: expected x [Z,M,K], weight [Z,N,K]")
     for name, t in (("x", x), ("weight", weight)):
@@ -311,10 +315,15 @@ def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
     L = _lib.load()
     nbytes = L.skinny_gemm_batched_workspace_bytes(Z, M, N, K, splits)
     ws = _workspace(nbytes, x.device)
-    rc = L.skinny_gemm_f16_batched(Z, M, N, K, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), weight.stride(1),
+    karr = None
+    if k_of is not None:
+        if len(k_of) != Z:
+            raise _lib.ChirrupAmdError("k_of: one reduction length per problem")
+        karr = (ctypes.c_int * Z)(*[int(k) for k in k_of])
+    rc = L.skinny_gemm_f16_grouped(Z, M, N, K, karr, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), weight.stride(1),
                                    weight.stride(0), _ptr(bias), bias_bs, out.data_ptr(), out.stride(1), out.stride(0), act,
                                    splits, ws.data_ptr(), _stream())
-    _lib.check(rc, "skinny_gemm_f16_batched")
+    _lib.check(rc, "skinny_gemm_f16_grouped")
     return out
 
 

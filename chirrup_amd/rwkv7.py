@@ -77,7 +77,7 @@ class _Layer:
 
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
-                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lbias", "f_K8", "f_V8", "f_V_rows")
+                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -108,6 +108,8 @@ class _Layer:
         downs, ups = (self.v1, self.w1, self.a1, self.g1), (self.v2, self.w2, self.a2, self.g2)
         dmax = max(t.shape[0] for t in downs)
         dmax = (dmax + 63) // 64 * 64              # whole 64-wide K-blocks for the MFMA kernels
+        # real ranks rounded up to whole K-blocks: what the up-projection has to multiply (the rest is padding)
+        self.lora_k = [min(dmax, (t.shape[0] + 63) // 64 * 64) for t in downs]
         self.lora1 = torch.zeros((4, dmax, C), dtype=DTYPE, device=dev)
         self.lora2 = torch.zeros((4, C, dmax), dtype=DTYPE, device=dev)
         for j, (d_, u_, n) in enumerate(zip(downs, ups, "vwag")):
@@ -360,7 +362,7 @@ class RWKV_x070:
         H, rows, dev = self.n_head, B * T, x.device
         x = x.contiguous()
         new = lambda *shape: torch.empty(shape, dtype=DTYPE, device=dev)
-        mixed, kin, o_in = new(6, B, T, C), new(1, B, T, C), new(B, T, C)
+        mixed, kin, o_in = new(6, rows, C), new(1, B, T, C), new(B, T, C)
         if not self.fuse_tmix_core:
             y, neg_kk, kka = new(B, T, C), new(B, T, C), new(B, T, C)
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
@@ -393,16 +395,17 @@ class RWKV_x070:
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
-                hid = torch.bmm(mixed[2 + p0:6].view(4 - p0, rows, C), lw.lora1[p0:].transpose(1, 2))
+                hid = torch.bmm(mixed[2 + p0:6], lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
                 if use_parts and self.skinny_lora_up and hid.shape[2] % 64 == 0:
-                    up = ops.skinny_bmm(hid, lw.lora2[p0:], lw.lbias[p0:], splits=1)            # bias in the epilogue
+                    up = ops.skinny_bmm(hid, lw.lora2[p0:], lw.lbias[p0:], splits=1,             # bias in the epilogue;
+                                        k_of=lw.lora_k[p0:])                                   # padding of the ranks not read
                 else:
                     up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))     # + v0 / w0 / a0 / 0
             if use_parts and self.skinny_rkv:
-                rkv = ops.skinny_bmm(mixed[0:3].view(3, rows, C), lw.rkv, splits=2)          # one launch for R, K, V
+                rkv = ops.skinny_bmm(mixed[0:3], lw.rkv, splits=2)                             # one launch for R, K, V
             else:
-                rkv = torch.bmm(mixed[0:3].view(3, rows, C), lw.rkv.transpose(1, 2))
+                rkv = torch.bmm(mixed[0:3], lw.rkv.transpose(1, 2))
             if side is not None:
                 main.wait_stream(side)
                 hid.record_stream(main), up.record_stream(main)

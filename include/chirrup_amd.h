@@ -175,6 +175,12 @@ int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int K, int spli
 int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W, int64_t ldw,
                             int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs, int act,
                             int splits, void *workspace, void *stream);
+/* The same with a reduction length per problem: problem z uses only the first k_of[z] columns of X[z] and W[z]
+ * (k_of[z] <= K, multiple of 64; NULL = K for all).  Operands zero-padded to a common K (the LoRA ranks 96/128/128/480
+ * packed as 512) are then not streamed beyond their real rank.  Z <= 8; splits must be 1 when k_of is given. */
+int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs, const void *W,
+                            int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs,
+                            int act, int splits, void *workspace, void *stream);
 /* Kernel variant (A/B switch): 0 register-staged; 1 both operands through one LDS-DMA ring loaded by the compute
  * waves; 2 per-wave x / W loader roles; 3 (default) four dedicated loader waves (see skinny_gemm.hip). */
 void skinny_gemm_select(int mode);

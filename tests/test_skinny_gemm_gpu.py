@@ -114,3 +114,28 @@ def test_skinny_bmm_matches_fp64(Z, M, N, K, splits, bias, act):
         for z in range(Z):
             y1 = ops.skinny_linear(x[z], w[z], None if b is None else b[z, 0], splits=splits)
             assert torch.equal(y1, y[z])
+
+
+def test_grouped_reduction_lengths_skip_zero_padding():
+    """k_of: problems zero-padded to a common K give the same bits whether the padding is streamed or not
+    (RWKV-7 LoRA up-projections: ranks 128 / 128 / 128 / 512 packed as 512)."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(5)
+    Z, M, N, K, ks = 4, 200, 4096, 512, [128, 64, 128, 512]
+    x = torch.zeros(Z, M, K, device="cuda", dtype=torch.float16)
+    w = torch.zeros(Z, N, K, device="cuda", dtype=torch.float16)
+    for z, k in enumerate(ks):
+        x[z, :, :k] = torch.randn(M, k, device="cuda").half()
+        w[z, :, :k] = (torch.randn(N, k, device="cuda") / k ** 0.5).half()
+    b = torch.randn(Z, 1, N, device="cuda").half()
+    full = ops.skinny_bmm(x, w, b, splits=1)
+    x[:, :, :] = torch.where(x == 0, torch.full_like(x, 7.0), x)        # poison what must not be read
+    for z, k in enumerate(ks):
+        x[z, :, :k] = torch.where(x[z, :, :k] == 7.0, torch.zeros_like(x[z, :, :k]), x[z, :, :k])
+    grouped = ops.skinny_bmm(x, w, b, splits=1, k_of=ks)
+    assert torch.equal(full, grouped)
+    want = torch.bmm(torch.where(x == 7.0, torch.zeros_like(x), x).double(), w.double().transpose(1, 2)) + b.double()
+    assert bool(((grouped.double() - want).abs() <= 2e-3 * want.abs().clamp_min(1.0)).all())
+    with pytest.raises(Exception):
+        ops.skinny_bmm(x, w, b, splits=2, k_of=ks)
