@@ -45,6 +45,7 @@ def parse():
     p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
+    p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     return p.parse_args()
@@ -227,6 +228,8 @@ def main():
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:
         model.skinny_rkv = bool(a.skinny_rkv)
+    if a.group_tmix is not None:
+        model.group_tmix_gemms = bool(a.group_tmix)
     if a.skinny_lora_up is not None:
         model.skinny_lora_up = bool(a.skinny_lora_up)
     state = make_state(model, B)

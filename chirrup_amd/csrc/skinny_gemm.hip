@@ -82,6 +82,19 @@ struct BatchStrides {
     int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
 };
 
+// Problems that share only M, K, ldx, ldw and the split count (a "grouped" launch: R/K/V and the four LoRA
+// down-projections of one RWKV-7 layer are seven such problems): everything else per problem.  used = 0: not grouped.
+struct GroupTable {
+    const f16 *X[8];
+    const void *W[8];
+    f16 *Y[8];
+    const f16 *bias[8];
+    float *part[8];
+    int N[8], ldy[8], act[8];      // act: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (reduce kernel)
+    int first[9];                  // N-groups before problem p (gridDim.x = first[used]): no workgroup without a tile --
+    int used;                      // an empty one would still wait for its 132 KiB of LDS before it could leave
+};
+
 template <int MT, bool W8, int EPI>
 __global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
@@ -256,7 +269,7 @@ template <int MT, bool W8, int EPI, int XD, int WD, int RM>
 __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
     const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
-    const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs) {
+    const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
     static_assert(RM == 1 || XD == WD, "one ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int kXBytes = MT * 32 * 128;            // x K-block image
@@ -272,14 +285,23 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
     const int lt = RM == 1 ? (tid & 127) : (tid & 255), lw = RM == 1 ? (wave & 1) : (wave & 3);
     int ngroup, kslice, batch;
     tile_of_block(ngroup, kslice, batch);
-    X += batch * bs.x;
-    Wv = static_cast<const unsigned char *>(Wv) + batch * bs.w * (W8 ? 1 : 2);
-    if (Y) Y += batch * bs.y;
-    if (bias) bias += batch * bs.bias;
-    if (part) part += (int64_t)batch * gridDim.y * M * N;
+    int Np = N, ldyp = ldy;
+    if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
+        batch = 0;
+        while (batch + 1 < gt.used && ngroup >= gt.first[batch + 1]) batch++;
+        ngroup -= gt.first[batch];
+        X = gt.X[batch], Wv = gt.W[batch], Y = gt.Y[batch], bias = gt.bias[batch], part = gt.part[batch];
+        Np = gt.N[batch], ldyp = gt.ldy[batch];
+    } else {
+        X += batch * bs.x;
+        Wv = static_cast<const unsigned char *>(Wv) + batch * bs.w * (W8 ? 1 : 2);
+        if (Y) Y += batch * bs.y;
+        if (bias) bias += batch * bs.bias;
+        if (part) part += (int64_t)batch * gridDim.y * M * N;
+    }
     const int n_base = ngroup * kBN;
     const int n0 = n_base + wave * 32;
-    const bool wave_live = computes && n0 < N;
+    const bool wave_live = computes && n0 < Np;
     const int k_begin = kslice * k_slice;
     const int Kz = (batch < 8 && bs.k[batch] > 0) ? bs.k[batch] : K;
     const int k_end = (k_begin + k_slice) < Kz ? (k_begin + k_slice) : Kz;
@@ -318,14 +340,14 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
                 const int nr = g >> 2;
                 const int lc = (g & 3) ^ ((nr >> 2) & 3);
                 int n = n_base + nr;
-                n = n < N ? n : N - 1;
+                n = n < Np ? n : Np - 1;
                 __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const uint8_t *>(Wv) + (int64_t)n * ldw + k0 + lc * 16),
                                                  (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
             } else {
                 const int nr = g >> 3;
                 const int lc = (g & 7) ^ ((nr >> 1) & 7);
                 int n = n_base + nr;
-                n = n < N ? n : N - 1;
+                n = n < Np ? n : Np - 1;
                 __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const f16 *>(Wv) + (int64_t)n * ldw + k0 + lc * 8),
                                                  (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
             }
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const int n = n0 + 8 * g + 4 * h;
-            if (n >= N) continue;
+            if (n >= Np) continue;
             if (EPI == EPI_F16) {
                 f16x4 o;
 #pragma unroll
@@ -417,10 +439,10 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
                     if (bias) v += (float)bias[n + e];
                     o[e] = (f16)v;
                 }
-                *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+                *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldyp + n) = o;
             } else {
                 const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * N + n) = o;
+                *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * Np + n) = o;
             }
         }
     }
@@ -438,32 +460,41 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const i
                                                             const float *__restrict__ part, const f16 *__restrict__ bias,
                                                             const f16 *__restrict__ rx, const f16 *__restrict__ mx,
                                                             const float *__restrict__ S, const int mode,
-                                                            f16 *__restrict__ Y, const int ldy, const int64_t y_bs = 0,
-                                                            const int64_t bias_bs = 0) {
+                                                            f16 *__restrict__ Y, int ldy, const int64_t y_bs = 0,
+                                                            const int64_t bias_bs = 0, const GroupTable gt = GroupTable{}) {
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t total = (int64_t)M * N / 4;
-    if (gi >= total) return;
     const int z = blockIdx.y;
-    part += (int64_t)z * splits * M * N;
-    Y += z * y_bs;
-    if (bias) bias += z * bias_bs;
-    const int m = (int)(gi / (N / 4)), n = (int)(gi % (N / 4)) * 4;
+    int N_ = N;
+    const bool mm8 = !gt.used && (mode == 2 || mode == 3);
+    int act = (mode == 1 || mode == 3) ? 1 : 0;        // 0 none, 1 relu^2, 2 tanh, 3 sigmoid
+    if (mode >= 4) act = (z + mode - 4) == 1 ? 2 : ((z + mode - 4) == 3 ? 3 : 0);
+    if (gt.used) {
+        N_ = gt.N[z], ldy = gt.ldy[z], part = gt.part[z], Y = gt.Y[z], bias = gt.bias[z];
+        act = gt.act[z];
+    }
+    const int64_t total = (int64_t)M * N_ / 4;
+    if (gi >= total) return;
+    if (!gt.used) {
+        part += (int64_t)z * splits * M * N;
+        Y += z * y_bs;
+        if (bias) bias += z * bias_bs;
+    }
+    const int m = (int)(gi / (N_ / 4)), n = (int)(gi % (N_ / 4)) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N + n);
+    for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N_ + n);
     f16x4 o;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         float v = s[e];
-        if (mode == 2 || mode == 3) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
+        if (mm8) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
         else if (bias) v += (float)bias[n + e];
-        if (mode == 1 || mode == 3) {
+        if (act == 1) {
             v = (float)(f16)v;                       // relu(fp16(y))**2, rwkv7.py:678
             v = v > 0.f ? v * v : 0.f;
-        } else if (mode >= 4) {
-            const int plane = z + mode - 4;
-            v = (float)(f16)v;
-            if (plane == 1) v = tanhf(v);
-            else if (plane == 3) v = 1.f / (1.f + __expf(-v));
+        } else if (act == 2) {
+            v = tanhf((float)(f16)v);
+        } else if (act == 3) {
+            v = 1.f / (1.f + __expf(-(float)(f16)v));
         }
         o[e] = (f16)v;
     }
@@ -556,7 +587,7 @@ int pick_splits(int N, int K, int requested, int Z = 1) {
 // MODE 1: one ring, every wave loads both operands; 2: x / W loader roles, x 2 slots / W 6 (u8: 8); 3: dedicated loader waves
 template <bool W8, int EPI, int MODE>
 int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs) {
+                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs, const GroupTable &gt) {
     constexpr int RM = MODE - 1;
     constexpr int XD = MODE == 2 ? 2 : (W8 ? 4 : 3);
     constexpr int WD = MODE == 2 ? (W8 ? 8 : 6) : XD;
@@ -570,7 +601,7 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
                                       (int)lds);                                                                          \
             lds_limit_raised = true;                                                                                      \
         }                                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs); \
+        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
     } while (0)
     switch (MT) {
         case 1: GO(1); break;
@@ -588,11 +619,12 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
 
 template <bool W8, int EPI>
 int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{}) {
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
+                const GroupTable &gt = GroupTable{}) {
     switch (g_mode) {
-        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
-        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
-        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs);
+        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
+        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
+        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
     }
 }
 
@@ -693,6 +725,54 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
         rc = (int)hipGetLastError();
     }
     return rc;
+}
+
+extern "C" int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int splits) {
+    if (count <= 0 || count > 8 || !problems || M <= 0 || splits <= 0) return 0;
+    int64_t b = 0;
+    for (int i = 0; i < count; i++) b += ((int64_t)splits * M * problems[i].n * (int64_t)sizeof(float) + 255) / 256 * 256;
+    return b;
+}
+
+// Up to 8 GEMMs that share M, K, the row strides of x and W and the split count, in ONE launch (+ one reduce launch):
+// y_i = act_i(x_i . w_i^T + bias_i).  Always goes through split-K partials (splits >= 1) so that the activations run in
+// the reduce kernel; workgroups are dealt over the largest problem's N-groups, the smaller problems' spare ones exit.
+extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw,
+                                     int splits, void *workspace, void *stream) {
+    if (count <= 0 || count > 8 || !problems) return CHIRRUP_E_SHAPE;
+    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || splits <= 0 ||
+        ((K / kKB) % splits))
+        return CHIRRUP_E_SHAPE;
+    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return workspace ? CHIRRUP_E_ALIGN : CHIRRUP_E_NULL;
+    if (!g_mode) return CHIRRUP_E_UNSUPPORTED;
+    GroupTable gt{};
+    gt.used = count;
+    int max_n = 0;
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    for (int i = 0; i < count; i++) {
+        const chirrup_gemm_problem &q = problems[i];
+        if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
+        if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
+        if ((reinterpret_cast<uintptr_t>(q.x) & 15) || (reinterpret_cast<uintptr_t>(q.w) & 15) || (reinterpret_cast<uintptr_t>(q.y) & 7))
+            return CHIRRUP_E_ALIGN;
+        gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y);
+        gt.bias[i] = static_cast<const f16 *>(q.bias), gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act;
+        gt.part[i] = reinterpret_cast<float *>(ws);
+        ws += ((int64_t)splits * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
+        max_n = q.n > max_n ? q.n : max_n;
+        gt.first[i + 1] = gt.first[i] + (q.n + kBN - 1) / kBN;
+    }
+    const int MT = (M + 31) / 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(gt.first[count], splits, 1);
+    int rc = launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, max_n, K, K / splits, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
+                                             nullptr, gt.part[0], BatchStrides{}, gt);
+    if (rc) return rc;
+    const int64_t total = (int64_t)M * max_n / 4;
+    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, M, max_n, splits,
+                       (const float *)nullptr, (const f16 *)nullptr, nullptr, nullptr, nullptr, 0, (f16 *)nullptr, 0, (int64_t)0,
+                       (int64_t)0, gt);
+    return (int)hipGetLastError();
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,

@@ -327,6 +327,42 @@ def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_
     return out
 
 
+class _GemmProblem(ctypes.Structure):
+    """chirrup_gemm_problem of include/chirrup_amd.h"""
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("n", ctypes.c_int), ("ldy", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+_GROUP_ACTS = {None: 0, "relu_sq": 1, "tanh": 2, "sigmoid": 3}
+
+
+def skinny_group(problems, splits: int = 2):
+    """Several GEMMs over the same rows in ONE launch (+ one reduce): ``problems`` is a list of
+    (x [M,K], weight [N,K], out [M,N], bias [N] or None, act in {None, "relu_sq", "tanh", "sigmoid"}); all x share
+    M <= 256, K (% 64 * splits == 0) and their row stride, all weights share their row stride.  Writes the outs."""
+    if not 0 < len(problems) <= 8:
+        raise _lib.ChirrupAmdError("skinny_group: 1..8 problems")
+    x0, w0 = problems[0][0], problems[0][1]
+    M, K = x0.shape
+    arr = (_GemmProblem * len(problems))()
+    for i, (x, w, out, bias, act) in enumerate(problems):
+        for name, t in (("x", x), ("weight", w), ("out", out)):
+            if not t.is_cuda or t.dtype != torch.float16 or t.dim() != 2 or t.stride(1) != 1:
+                raise _lib.ChirrupAmdError(f"{name}: expected a GPU fp16 matrix with unit inner stride")
+        if tuple(x.shape) != (M, K) or w.shape[1] != K or x.stride(0) != x0.stride(0) or w.stride(0) != w0.stride(0) \
+                or tuple(out.shape) != (M, w.shape[0]):
+            raise _lib.ChirrupAmdError("skinny_group: problems must share M, K and the row strides of x and weight")
+        if bias is not None:
+            _chk16("bias", bias, w.shape[0])
+        arr[i] = _GemmProblem(x.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias) or None, w.shape[0], out.stride(0), _GROUP_ACTS[act])
+    L = _lib.load()
+    nbytes = L.skinny_gemm_group_workspace_bytes(len(problems), ctypes.addressof(arr), M, splits)
+    ws = _workspace(nbytes + 256, x0.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), w0.stride(0), splits, base, _stream())
+    _lib.check(rc, "skinny_gemm_f16_group")
+
+
 def skinny_linear_partial(x, weight, splits: int, partials):
     """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
     [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""

@@ -171,6 +171,7 @@ class RWKV_x070:
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
+        self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_ffn_key = False                      # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
@@ -392,9 +393,23 @@ class RWKV_x070:
             p0 = 1 if i == 0 else 0                                                           # layer 0 has no v gate
             main = torch.cuda.current_stream()
             side = self._side if self.overlap_lora else None
+            grouped = use_parts and self.group_tmix_gemms
+            if grouped:
+                # ONE launch for R/K/V and the LoRA down-projections (+ their activations in its reduce), then the
+                # LoRA up-projections, all on this stream: no cross-stream edges (they cost ~19 us per layer)
+                rkv = new(3, rows, C)
+                hid = new(4 - p0, rows, lw.lora1.shape[1])         # columns past a problem's rank are never read
+                probs = [(mixed[j], lw.rkv[j], rkv[j], None, None) for j in range(3)]
+                for j in range(p0, 4):
+                    kj = lw.lora_k[j]
+                    probs.append((mixed[2 + j], lw.lora1[j, :kj], hid[j - p0, :, :kj], None, ("tanh" if j == 1 else ("sigmoid" if j == 3 else None))))
+                ops.skinny_group(probs, splits=2)
+                up = ops.skinny_bmm(hid[: 4 - p0], lw.lora2[p0:], lw.lbias[p0:], splits=1, k_of=lw.lora_k[p0:])
+                side = None
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
+              if not grouped:
                 hid = torch.bmm(mixed[2 + p0:6], lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
                 if use_parts and self.skinny_lora_up and hid.shape[2] % 64 == 0:
@@ -402,7 +417,9 @@ class RWKV_x070:
                                         k_of=lw.lora_k[p0:])                                   # padding of the ranks not read
                 else:
                     up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))     # + v0 / w0 / a0 / 0
-            if use_parts and self.skinny_rkv:
+            if grouped:
+                pass
+            elif use_parts and self.skinny_rkv:
                 rkv = ops.skinny_bmm(mixed[0:3], lw.rkv, splits=2)                             # one launch for R, K, V
             else:
                 rkv = torch.bmm(mixed[0:3], lw.rkv.transpose(1, 2))

@@ -181,6 +181,22 @@ int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, 
 int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs, const void *W,
                             int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs,
                             int act, int splits, void *workspace, void *stream);
+/* Up to 8 GEMMs that share M, K, the row strides of x and W (ldx, ldw) and the split count, in ONE launch plus one
+ * reduce launch: y_i = act_i(x_i . w_i^T + bias_i), w_i binary16 [n_i][K].  This is one RWKV-7 layer's receptance /
+ * key / value projections together with its four LoRA down-projections and their activations (Albatross/rwkv7.py:
+ * 625-637): seven independent GEMMs over the same token rows that the reference issues one by one.
+ * act: 0 none, 1 relu(.)^2, 2 tanh, 3 sigmoid (applied to the binary16-rounded sum, like a separate torch op).
+ * workspace: skinny_gemm_group_workspace_bytes(...) bytes, 256-byte aligned. */
+typedef struct {
+    const void *x;     /* [M][ldx] binary16 */
+    const void *w;     /* [n][ldw] binary16 */
+    void *y;           /* [M][ldy] binary16 */
+    const void *bias;  /* [n] binary16 or NULL */
+    int n, ldy, act;
+} chirrup_gemm_problem;
+int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int splits);
+int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
+                          void *workspace, void *stream);
 /* Kernel variant (A/B switch): 0 register-staged; 1 both operands through one LDS-DMA ring loaded by the compute
  * waves; 2 per-wave x / W loader roles; 3 (default) four dedicated loader waves (see skinny_gemm.hip). */
 void skinny_gemm_select(int mode);

@@ -139,3 +139,32 @@ def test_grouped_reduction_lengths_skip_zero_padding():
     assert bool(((grouped.double() - want).abs() <= 2e-3 * want.abs().clamp_min(1.0)).all())
     with pytest.raises(Exception):
         ops.skinny_bmm(x, w, b, splits=2, k_of=ks)
+
+
+def test_grouped_launch_of_unequal_problems():
+    """One launch for problems of different N with their own activations (R/K/V + the LoRA down-projections of a
+    layer): each against fp64 and, for the plain ones, bit-equal to the single-problem kernel at the same split."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(9)
+    M, K = 200, 4096
+    mixed = torch.randn(6, M, K, device="cuda").half()
+    rkv = (torch.randn(3, 4096, K, device="cuda") / K ** 0.5).half()
+    lora1 = (torch.randn(4, 512, K, device="cuda") / K ** 0.5).half()
+    ranks = [128, 128, 128, 512]
+    out_rkv = torch.empty(3, M, 4096, device="cuda", dtype=torch.float16)
+    hid = torch.zeros(4, M, 512, device="cuda", dtype=torch.float16)
+    acts = [None, "tanh", None, "sigmoid"]
+    probs = [(mixed[j], rkv[j], out_rkv[j], None, None) for j in range(3)]
+    probs += [(mixed[2 + j], lora1[j, :ranks[j]], hid[j, :, :ranks[j]], None, acts[j]) for j in range(4)]
+    ops.skinny_group(probs, splits=2)
+    for j in range(3):
+        want = mixed[j].double() @ rkv[j].double().t()
+        assert bool(((out_rkv[j].double() - want).abs() <= 2e-3 * want.abs().clamp_min(1.0)).all())
+        assert torch.equal(out_rkv[j], ops.skinny_linear(mixed[j], rkv[j], splits=2))
+    for j in range(4):
+        want = (mixed[2 + j].double() @ lora1[j, :ranks[j]].double().t()).half().double()
+        want = torch.tanh(want) if acts[j] == "tanh" else (torch.sigmoid(want) if acts[j] == "sigmoid" else want)
+        got = hid[j, :, :ranks[j]].double()
+        assert bool(((got - want).abs() <= 2e-3 * want.abs().clamp_min(1.0)).all()), j
+        assert float(hid[j, :, ranks[j]:].abs().max()) == 0.0 if ranks[j] < 512 else True      # nothing written past N
