@@ -169,6 +169,7 @@ class RWKV_x070:
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
+        self.skinny_min_rows = 33                        # ... and from this many rows up (7.2B: equal at 32, -8 % at 64, slower at 16)
         self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
@@ -369,7 +370,7 @@ class RWKV_x070:
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
         dparts = None                     # split-K partials of the previous ffn.value GEMM (summed by the next LN kernel)
-        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and 64 < rows <= 256
+        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and self.skinny_min_rows <= rows <= 256
                      and C >= self.skinny_min_embd)
         pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
 
