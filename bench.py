@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
     p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
     p.add_argument("--skinny-min-rows", type=int, default=None, help="lower row bound of the hand-written GEMM path, A/B only")
+    p.add_argument("--skinny-att-out", type=int, default=None, help="1/0: att.output through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     return p.parse_args()
@@ -229,6 +230,8 @@ def main():
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:
         model.skinny_rkv = bool(a.skinny_rkv)
+    if a.skinny_att_out is not None:
+        model.skinny_att_out = bool(a.skinny_att_out)
     if a.skinny_min_rows is not None:
         model.skinny_min_rows = a.skinny_min_rows
     if a.group_tmix is not None:

@@ -572,7 +572,11 @@ int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, i
 int g_mode = 3;             // 0: register-staged kernel; 1-3: LDS-DMA ring kernel variants (launch_ring_mode); 3 measured fastest
 
 int pick_splits(int N, int K, int requested, int Z = 1) {
-    if (requested > 0) return requested;
+    if (requested > 0) {                               // a request is honoured as far as K allows: whole, equal K-blocks
+        int s = requested < K / kKB ? requested : K / kKB;
+        while (s > 1 && (K / kKB) % s) s--;
+        return s < 1 ? 1 : s;
+    }
     const int ngroups = Z * ((N + kBN - 1) / kBN);
     int s = (256 + ngroups - 1) / ngroups;             // aim at >= 256 workgroups
     const int max_s = K / 256 > 0 ? K / 256 : 1;       // keep >= 4 K-blocks per slice

@@ -174,7 +174,9 @@ class RWKV_x070:
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
-        self.skinny_ffn_key = False                      # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
+        self.skinny_wide_rows = 129                      # att.output / ffn.key join the hand-written path from here (M = 64: library faster)
+        self.skinny_att_out = True                       # att.output through the ring kernel, its reduce folded into LN2
+        self.skinny_ffn_key = True                       # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -373,6 +375,8 @@ class RWKV_x070:
         use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and self.skinny_min_rows <= rows <= 256
                      and C >= self.skinny_min_embd)
         pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
+        pbuf_o = (torch.empty((8, rows, C), dtype=torch.float32, device=dev)
+                  if (use_parts and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
 
         def commit_carry(prev):
             if slot_idx is None:
@@ -444,18 +448,23 @@ class RWKV_x070:
                     v_first = v
                 self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
                 ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
-            att = F.linear(o_in, lw.O)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
-            ops.add_ln_mix(B, T, C, x, att, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
-                           lw.f_x_k.view(1, C), kin, slot_idx)
+            if use_parts and self.skinny_att_out and rows >= self.skinny_wide_rows:
+                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O, 8, pbuf_o)   # reduce folded into the LN below
+                ops.add_ln_mix(B, T, C, x, None, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
+                               lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
+            else:
+                att = F.linear(o_in, lw.O)
+                ops.add_ln_mix(B, T, C, x, att, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
+                               lw.f_x_k.view(1, C), kin, slot_idx)
             if T > 1:
                 commit_carry(prev)
             if self.ffn_dtype == torch.int8:        # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1)
                 delta = ops.mm8t_linear(kf, *lw.f_V8).view(B, T, C)
             else:
-                if use_parts and self.skinny_ffn_key:
+                if use_parts and self.skinny_ffn_key and rows >= self.skinny_wide_rows:
                     kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K, act=1, splits=2)
                 else:
                     kf = F.linear(kin[0], lw.f_K)
