@@ -13,7 +13,8 @@ import threading
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchirrup_amd.so")
+# CHIRRUP_AMD_LIB: another build of the same ABI (A/B of kernel variants, tools/); default: the in-tree library
+LIB_PATH = os.environ.get("CHIRRUP_AMD_LIB") or os.path.join(_HERE, "libchirrup_amd.so")
 _lib = None
 _lock = threading.Lock()      # worker threads may race to the first load
 
