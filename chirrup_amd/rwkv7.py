@@ -372,11 +372,13 @@ class RWKV_x070:
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         delta, v_first = None, None
         dparts = None                     # split-K partials of the previous ffn.value GEMM (summed by the next LN kernel)
-        use_parts = (self.skinny_ffn_value and self.ffn_dtype == torch.float16 and self.skinny_min_rows <= rows <= 256
-                     and C >= self.skinny_min_embd)
+        # decode-batch regime of the hand-written MFMA GEMMs: time-mix projections for either FFN dtype (`hw`), the fp16
+        # FFN matrices on top of that (`use_parts`; the mm8 FFN has its own kernels)
+        hw = self.skinny_ffn_value and self.skinny_min_rows <= rows <= 256 and C >= self.skinny_min_embd
+        use_parts = hw and self.ffn_dtype == torch.float16
         pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
         pbuf_o = (torch.empty((8, rows, C), dtype=torch.float32, device=dev)
-                  if (use_parts and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
+                  if (hw and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
 
         def commit_carry(prev):
             if slot_idx is None:
@@ -398,7 +400,7 @@ class RWKV_x070:
             p0 = 1 if i == 0 else 0                                                           # layer 0 has no v gate
             main = torch.cuda.current_stream()
             side = self._side if self.overlap_lora else None
-            grouped = use_parts and self.group_tmix_gemms
+            grouped = hw and self.group_tmix_gemms
             if grouped:
                 # ONE launch for R/K/V and the LoRA down-projections (+ their activations in its reduce), then the
                 # LoRA up-projections, all on this stream: no cross-stream edges (they cost ~19 us per layer)
@@ -417,14 +419,14 @@ class RWKV_x070:
               if not grouped:
                 hid = torch.bmm(mixed[2 + p0:6], lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
-                if use_parts and self.skinny_lora_up and hid.shape[2] % 64 == 0:
+                if hw and self.skinny_lora_up and hid.shape[2] % 64 == 0:
                     up = ops.skinny_bmm(hid, lw.lora2[p0:], lw.lbias[p0:], splits=1,             # bias in the epilogue;
                                         k_of=lw.lora_k[p0:])                                   # padding of the ranks not read
                 else:
                     up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))     # + v0 / w0 / a0 / 0
             if grouped:
                 pass
-            elif use_parts and self.skinny_rkv:
+            elif hw and self.skinny_rkv:
                 rkv = ops.skinny_bmm(mixed[0:3], lw.rkv, splits=2)                             # one launch for R, K, V
             else:
                 rkv = torch.bmm(mixed[0:3], lw.rkv.transpose(1, 2))
@@ -450,7 +452,7 @@ class RWKV_x070:
                 ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
-            if use_parts and self.skinny_att_out and rows >= self.skinny_wide_rows:
+            if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
                 aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O, 8, pbuf_o)   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
                                lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
