@@ -1,25 +1,33 @@
-// Skinny-M MFMA GEMM for the decode step:  Y[M][N] = X[M][K] . W[N][K]^T   (M <= 256 batch rows)
-// with binary16 or uint8 (mm8) weights, binary32 accumulation.
+// Skinny-M MFMA GEMMs for the decode step:  Y[M][N] = X[M][K] . W[N][K]^T   (M <= 256 token rows)
+// with binary16 or uint8 (mm8) weights, binary32 accumulation.  One RWKV-7 layer at 33..256 rows runs five launches of
+// the ring kernel below: R/K/V + the four LoRA down-projections (grouped), the four LoRA up-projections (batched, per-
+// problem reduction length), att.output, ffn.key, ffn.value (DESIGN.md sections 4-5 have the measurements).
 //
-// Why a hand-written kernel: at M = 200 the library GEMMs (hipBLASLt through torch) reach only
-// 1.4-2.8 TB/s of weight streaming (profiles/r01_step_v3_*): every 64x64 output tile re-reads its
-// x rows AND its W rows, so each CU ingests far more than its share of W.
-// Here the batch is small enough that ONE workgroup holds all M rows of x for its K-block in LDS:
-//   * workgroup = 4 waves; wave w owns 32 output columns (rows of W) -- W is streamed HBM ->
-//     VGPRs exactly once, 64 contiguous bytes per lane per K-block (full 128-B lines per W row),
-//     never through LDS ("GEMV / M <= 16 decode weights" rule of the CDNA guide, extended to
-//     M <= 256 by sharing x instead of W);
-//   * the x K-block [M][64] is staged once per workgroup through registers into a double-buffered,
-//     XOR-swizzled LDS image (chunk c of row m at m*128 + ((c ^ ((m>>1)&7))<<4): conflict-free
-//     ds_read_b128 for the MFMA B fragments) and reused by all 4 waves; the loads of the next x block
-//     and of the W blocks two steps ahead stay in flight across the barrier (register staging on
-//     purpose: an LDS-DMA in flight would make every barrier a vmcnt(0) drain -- guide section 5);
-//   * v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m): one W fragment
-//     feeds MT = ceil(M/32) MFMAs, so u8 -> f16 conversion (mm8) costs 8 VALU per MT MFMAs;
-//   * optional split-K over blockIdx.y with binary32 partials + a reduce/epilogue kernel
-//     (bias, relu^2, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179).
-// K is consumed in a permuted order inside each 64-block (lane half h takes k = 32h + 8s + j at
-// MFMA step s) -- the same permutation on both operands, so the dot products are unchanged.
+// Why hand-written: at M = 200 the library GEMMs (hipBLASLt through torch) stream weights at 1.4-2.8 TB/s and every
+// projection is its own launch (or needs a side stream, whose graph edges cost ~19 us per layer).  Here the batch is
+// small enough that ONE workgroup holds all M rows of x for its K-block in LDS, and independent problems share a launch.
+//
+// skinny_gemm_ring_kernel (what ships, variant 3 of skinny_gemm_select):
+//   * workgroup = 4 compute waves + 4 loader waves.  A 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA
+//     (global_load_lds_dwordx4) into a 3-slot ring: x image MT*32 rows x 128 B, W image 128 rows x 128 B (u8: 64 B),
+//     both XOR-swizzled on the SOURCE address so that the ds_read_b128 of the MFMA fragments are conflict-free.  No
+//     load of the main loop has a register destination, so one hand-placed `s_waitcnt vmcnt(n)` + raw `s_barrier`
+//     per K-block keeps two whole stages in flight.  The loader waves exist because a wave is blocked while its
+//     LDS-DMA instructions issue; the compute waves spend that time in MFMAs.
+//   * compute wave w owns 32 rows of W: v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m);
+//     one W fragment feeds MT = ceil(M/32) MFMAs (u8 -> f16 by v_perm in registers).  __builtin_amdgcn_sched_barrier
+//     pins "read the next MT x fragments, then MT MFMAs": left alone the scheduler sinks every ds_read to its MFMA.
+//   * split-K over blockIdx.y with binary32 partials; the partials are reduced by skinny_reduce_kernel (bias, relu^2,
+//     tanh / sigmoid of the LoRA planes, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179) or by
+//     the NEXT layer-norm kernel (rwkv7_add_ln_mix, delta_partials).
+//   * batched (gridDim.z problems at uniform strides, optional per-problem K) and grouped launches (per-problem
+//     operands, N and output stride; blockIdx.x runs over an exact tile list -- an empty workgroup would still have to
+//     be given its 132 KiB of LDS before it could leave).
+//   * workgroup -> tile order is XCD-aware (tile_of_block).
+// skinny_gemm_kernel is the first, register-staged design (variant 0), kept for A/B: W streamed HBM -> VGPRs, x through a
+// double-buffered LDS image.  Variants 1 and 2 are intermediate forms of the ring kernel (every wave loads; x / W loader
+// roles).  K is consumed in a permuted order inside each 64-block (lane half h takes k = 32h + 8s + j at MFMA step s)
+// -- the same permutation on both operands, so the dot products are unchanged.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
