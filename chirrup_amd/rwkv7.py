@@ -11,12 +11,20 @@ plus ``forward / forward_batch / forward_seq_batch / forward_one / forward_seq``
 ``get_gpu_parameter_groups()`` with the same meaning.  It is NOT a copy of the reference's
 TorchScript module: the per-layer work is organised around the HIP kernels of this package
 
-    LN1 + token-shift + 6 lerps   ->  one fused kernel          (csrc/elementwise.hip)
-    R/K/V/O, LoRA, FFN, head      ->  hipBLASLt through torch.matmul (plain library GEMMs)
-    k/kk/a/v gating chain         ->  one fused kernel
-    WKV7 state update             ->  csrc/wkv7.hip (bit-exact spec A1)
-    group-norm + bonus + gate     ->  one fused kernel
-    LN2 + token-shift + lerp, relu^2  ->  fused kernels
+    residual add + LN1 + token-shift + 6 lerps (+ the split-K reduce of the previous ffn.value)
+                                   ->  one kernel                          (csrc/elementwise.hip)
+    R/K/V + the 4 LoRA down-projections (+ tanh / sigmoid)
+                                   ->  ONE grouped launch of the MFMA ring GEMM + its reduce   (csrc/skinny_gemm.hip)
+    the 4 LoRA up-projections + bias ->  one batched launch of the same kernel
+    k/kk/a/v gating + WKV7 state update (bit-exact spec A1) + group-norm + bonus + gate
+                                   ->  one kernel                          (csrc/wkv7.hip)
+    att.output, ffn.key (+ relu^2), ffn.value  ->  the ring GEMM; the reduces of att.output / ffn.value are folded
+                                       into the following LN kernel
+    residual add + LN2 + token-shift + lerp    ->  one kernel
+    head                                       ->  hipBLASLt through torch
+
+(that is the decode-batch regime, 33..256 token rows at C >= 4096; outside it -- a single stream, prefill chunks,
+small models -- the projections are library GEMMs and the LoRA chain overlaps R/K/V on a side stream)
 
 and the whole decode step can be captured in a HIP graph (`capture_decode_graph`).  With
 ``fused=False`` the same arithmetic runs as plain torch ops (one rounding to fp16 per op, exactly
@@ -354,7 +362,9 @@ class RWKV_x070:
 
     def _forward_embedded_fused(self, x, state, T, full_output, slot_idx=None):
         """Same arithmetic as _forward_embedded with every element-wise chain in one HIP kernel
-        (csrc/elementwise.hip).  x [B,T,C] is consumed (updated in place as the residual stream)."""
+        (csrc/elementwise.hip, csrc/wkv7.hip) and, in the decode-batch regime (`hw` below), every projection of the
+        layer through the MFMA ring GEMM (csrc/skinny_gemm.hip).  x [B,T,C] is consumed (updated in place as the
+        residual stream)."""
         z = self.z
         s0, s1, s2 = state
         if slot_idx is not None:
