@@ -41,6 +41,7 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
     p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
@@ -53,14 +54,14 @@ def parse():
     return p.parse_args()
 
 
-def build_model(name, device, fused, mm8=False):
+def build_model(name, device, fused, mm8=False, tiled=True):
     from chirrup_amd.rwkv7 import RWKV_x070, model_args
     from chirrup_amd.synth import CONFIGS, make_state_dict
 
     L, C = CONFIGS[name]
     zd = make_state_dict(L, C, 65536, seed=42, device=device)      # random-init weights of the architecture
     m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused,
-                  ffn_dtype=torch.int8 if mm8 else torch.float16)
+                  ffn_dtype=torch.int8 if mm8 else torch.float16, tiled_weights=tiled)
     del zd
     torch.cuda.empty_cache()
     return m
@@ -222,7 +223,7 @@ def main():
 
     L, C = CONFIGS[a.model]
     B = a.bsz
-    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8)
+    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled)
     if a.gemm_mode is not None:
         from chirrup_amd import lib
         lib.load().skinny_gemm_select(a.gemm_mode)
@@ -314,7 +315,8 @@ def main():
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
                                    "greedy decode step incl. sampling and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
-                       "graph": not a.no_graph, "fused_elementwise": not a.no_fused},
+                       "graph": not a.no_graph, "fused_elementwise": not a.no_fused,
+                       "tiled_weight_copies": bool(model.tiled_weights and model._layers[0].rkv_t is not None)},
             "roofline": {"bound": "hbm", "kernel": "wkv7_seq_kernel<1> (fused time-mix core)" if fused_core else "wkv7_seq_kernel<0>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_launch, "launch_us": round(wkv_ms * 1e3, 2),

@@ -88,6 +88,7 @@ __device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &bat
 struct BatchStrides {
     int64_t x, w, y, bias;
     int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
+    int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
 };
 
 // Problems that share only M, K, ldx, ldw and the split count (a "grouped" launch: R/K/V and the four LoRA
@@ -99,6 +100,7 @@ struct GroupTable {
     const f16 *bias[8];
     float *part[8];
     int N[8], ldy[8], act[8];      // act: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (reduce kernel)
+    int tiled[8];                  // W of problem p is in the tile-image layout
     int first[9];                  // N-groups before problem p (gridDim.x = first[used]): no workgroup without a tile --
     int used;                      // an empty one would still wait for its 132 KiB of LDS before it could leave
 };
@@ -294,12 +296,14 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
     int ngroup, kslice, batch;
     tile_of_block(ngroup, kslice, batch);
     int Np = N, ldyp = ldy;
+    bool w_tiled = bs.tiled != 0;
     if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
         batch = 0;
         while (batch + 1 < gt.used && ngroup >= gt.first[batch + 1]) batch++;
         ngroup -= gt.first[batch];
         X = gt.X[batch], Wv = gt.W[batch], Y = gt.Y[batch], bias = gt.bias[batch], part = gt.part[batch];
         Np = gt.N[batch], ldyp = gt.ldy[batch];
+        w_tiled = gt.tiled[batch] != 0;
     } else {
         X += batch * bs.x;
         Wv = static_cast<const unsigned char *>(Wv) + batch * bs.w * (W8 ? 1 : 2);
@@ -356,8 +360,11 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
                 const int lc = (g & 7) ^ ((nr >> 1) & 7);
                 int n = n_base + nr;
                 n = n < Np ? n : Np - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const f16 *>(Wv) + (int64_t)n * ldw + k0 + lc * 8),
-                                                 (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
+                // tile-image layout: the 16 KiB image of (N-group, K-block) is stored contiguously in LDS order, so a
+                // wave-instruction reads 1 KiB of consecutive bytes instead of eight 128-B pieces of eight rows
+                const f16 *src = w_tiled ? static_cast<const f16 *>(Wv) + ((int64_t)ngroup * (K / kKB) + k0 / kKB) * (kBN * kKB) + g * 8
+                                         : static_cast<const f16 *>(Wv) + (int64_t)n * ldw + k0 + lc * 8;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
             }
         }
     };
@@ -640,6 +647,34 @@ int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_sl
     }
 }
 
+namespace {
+// W [N][K] row-major -> tile images: tile (N-group g, K-block b) = 1024 chunks of 16 B in the order the ring kernel
+// keeps them in LDS (row nr = c >> 3 at chunk position c & 7 holds logical chunk (c & 7) ^ ((nr >> 1) & 7)).
+__global__ __launch_bounds__(256) void tile_weight_kernel(const int N, const int K, const f16 *__restrict__ W, const int64_t ldw,
+                                                          f16 *__restrict__ Wt) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * K / 8;
+    if (c >= total) return;
+    const int g = (int)(c & 1023);
+    const int64_t tile = c >> 10;
+    const int kb = (int)(tile % (K / kKB)), ng = (int)(tile / (K / kKB));
+    const int nr = g >> 3, lc = (g & 7) ^ ((nr >> 1) & 7);
+    *reinterpret_cast<f16x8 *>(Wt + c * 8) = *reinterpret_cast<const f16x8 *>(W + ((int64_t)ng * kBN + nr) * ldw + kb * kKB + lc * 8);
+}
+}  // namespace
+
+// Re-lay a binary16 weight matrix W [N][K] (N % 128 == 0, K % 64 == 0) as contiguous 16-KiB tile images for the ring
+// kernel (w_tiled = 1 in the GEMM calls).  Wt needs N*K elements; W and Wt must not overlap.
+extern "C" int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream) {
+    if (N <= 0 || K <= 0 || (N % kBN) || (K % kKB) || ldw < K || (ldw & 7)) return CHIRRUP_E_SHAPE;
+    if (!W || !Wt) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Wt) & 15)) return CHIRRUP_E_ALIGN;
+    const int64_t total = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, K, static_cast<const f16 *>(W), ldw, static_cast<f16 *>(Wt));
+    return (int)hipGetLastError();
+}
+
 extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const int s = pick_splits(N, K, splits);
@@ -647,10 +682,11 @@ extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) 
 }
 
 // Y = act(X . W^T + bias);  W binary16 [N][K] (row stride ldw).  act: 0 none, 1 relu^2.
-extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
-                               void *Y, int ldy, int act, int splits, void *workspace, void *stream) {
+extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
+                               const void *bias, void *Y, int ldy, int act, int splits, void *workspace, void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N || (ldx & 7) || (ldw & 7) || (ldy & 3))
         return CHIRRUP_E_SHAPE;
+    if (w_tiled && ((N % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
         return CHIRRUP_E_ALIGN;
@@ -663,11 +699,13 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     const dim3 grid((N + kBN - 1) / kBN, s);
     const size_t lds = (size_t)2 * MT * 32 * 128;
     int rc;
+    BatchStrides bs{};
+    bs.tiled = w_tiled ? 1 : 0;
     if (g_mode)
         rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y,
-                                                       ldy, (const f16 *)bias, (float *)workspace)
+                                                       ldy, (const f16 *)bias, (float *)workspace, bs)
                      : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
-                                                   (const f16 *)bias, (float *)workspace);
+                                                   (const f16 *)bias, (float *)workspace, bs);
     else
         rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                            (const f16 *)bias, (float *)workspace);
@@ -769,6 +807,8 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
             return CHIRRUP_E_ALIGN;
         gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y);
         gt.bias[i] = static_cast<const f16 *>(q.bias), gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act;
+        if (q.w_tiled && (q.n % kBN)) return CHIRRUP_E_UNSUPPORTED;
+        gt.tiled[i] = q.w_tiled ? 1 : 0;
         gt.part[i] = reinterpret_cast<float *>(ws);
         ws += ((int64_t)splits * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
         max_n = q.n > max_n ? q.n : max_n;
@@ -787,8 +827,8 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
     return (int)hipGetLastError();
 }
 
-extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
-                                       float *partials, void *stream) {
+extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
+                                       int splits, float *partials, void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7))
         return CHIRRUP_E_SHAPE;
     if (!X || !W || !partials) return CHIRRUP_E_NULL;
@@ -797,8 +837,11 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
     const int s = pick_splits(N, K, splits);
     const int MT = (M + 31) / 32;
     const dim3 grid((N + kBN - 1) / kBN, s);
+    if (w_tiled && ((N % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
+    BatchStrides bs{};
+    bs.tiled = w_tiled ? 1 : 0;
     const int rc = launch_ring<false, EPI_PARTIAL>(MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
-                                                   W, ldw, nullptr, N, nullptr, partials);
+                                                   W, ldw, nullptr, N, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
 }
 

@@ -267,16 +267,44 @@ def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=
     return out
 
 
+class TiledWeight:
+    """A [N, K] fp16 weight re-laid as 16-KiB tile images for the ring GEMM (include/chirrup_amd.h:
+    skinny_tile_weight).  Accepted wherever the skinny_* wrappers take a weight."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data: torch.Tensor, n: int, k: int):
+        self.data, self.shape = data, (n, k)
+
+
+def tile_weight(weight: torch.Tensor) -> TiledWeight:
+    """weight [N, K] fp16 (N % 128 == 0, K % 64 == 0, may be row-strided) -> a NEW tensor in the tile-image layout."""
+    if weight.dim() != 2 or not weight.is_cuda or weight.dtype != torch.float16 or weight.stride(1) != 1:
+        raise _lib.ChirrupAmdError("tile_weight: expected a GPU fp16 matrix with unit inner stride")
+    N, K = weight.shape
+    out = torch.empty((N * K,), dtype=torch.float16, device=weight.device)
+    rc = _lib.load().skinny_tile_weight(N, K, weight.data_ptr(), weight.stride(0), out.data_ptr(), _stream())
+    _lib.check(rc, "skinny_tile_weight")
+    return TiledWeight(out, N, K)
+
+
+def _weight_args(weight, K: int, name: str = "weight"):
+    """(N, data_ptr, row stride, w_tiled) of a plain [N, K] matrix or a TiledWeight."""
+    if isinstance(weight, TiledWeight):
+        if weight.shape[1] != K:
+            raise _lib.ChirrupAmdError(f"{name}: K mismatch")
+        return weight.shape[0], weight.data.data_ptr(), K, 1
+    if weight.dim() != 2 or weight.shape[1] != K or not weight.is_cuda or weight.dtype != torch.float16 or weight.stride(1) != 1:
+        raise _lib.ChirrupAmdError(f"{name}: expected a GPU fp16 [N, K] matrix with unit inner stride")
+    return weight.shape[0], weight.data_ptr(), weight.stride(0), 0
+
+
 def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
     """y = act(x @ weight.T + bias) through the hand-written skinny-M MFMA GEMM (x [M<=256, K] fp16,
-    weight [N, K] fp16 row-major, may be a row-strided view).  act 1 = relu(.)**2."""
-    if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
-        raise _lib.ChirrupAmdError("skinny_linear: expected x [M,K], weight [N,K]")
-    for name, t in (("x", x), ("weight", weight)):
-        if not t.is_cuda or t.dtype != torch.float16 or t.stride(1) != 1:
-            raise _lib.ChirrupAmdError(f"{name}: expected GPU fp16 with unit inner stride")
+    weight [N, K] fp16 row-major, may be a row-strided view, or a TiledWeight).  act 1 = relu(.)**2."""
+    if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float16 or x.stride(1) != 1:
+        raise _lib.ChirrupAmdError("skinny_linear: expected x [M,K] GPU fp16 with unit inner stride")
     M, K = x.shape
-    N = weight.shape[0]
+    N, wptr, ldw, w_tiled = _weight_args(weight, K)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float16, device=x.device)
     L = _lib.load()
@@ -286,7 +314,7 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None)
     ws = _workspace(nbytes, x.device) if nbytes else None
     if bias is not None:
         _chk16("bias", bias, N)
-    rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), _ptr(bias),
+    rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, _ptr(bias),
                            out.data_ptr(), out.stride(0), act, splits, _ptr(ws), _stream())
     _lib.check(rc, "skinny_gemm_f16")
     return out
@@ -330,7 +358,7 @@ def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_
 class _GemmProblem(ctypes.Structure):
     """chirrup_gemm_problem of include/chirrup_amd.h"""
     _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("bias", ctypes.c_void_p),
-                ("n", ctypes.c_int), ("ldy", ctypes.c_int), ("act", ctypes.c_int)]
+                ("n", ctypes.c_int), ("ldy", ctypes.c_int), ("act", ctypes.c_int), ("w_tiled", ctypes.c_int)]
 
 
 _GROUP_ACTS = {None: 0, "relu_sq": 1, "tanh": 2, "sigmoid": 3}
@@ -342,24 +370,30 @@ def skinny_group(problems, splits: int = 2):
     M <= 256, K (% 64 * splits == 0) and their row stride, all weights share their row stride.  Writes the outs."""
     if not 0 < len(problems) <= 8:
         raise _lib.ChirrupAmdError("skinny_group: 1..8 problems")
-    x0, w0 = problems[0][0], problems[0][1]
+    x0 = problems[0][0]
     M, K = x0.shape
     arr = (_GemmProblem * len(problems))()
+    ldw0 = None
     for i, (x, w, out, bias, act) in enumerate(problems):
-        for name, t in (("x", x), ("weight", w), ("out", out)):
+        for name, t in (("x", x), ("out", out)):
             if not t.is_cuda or t.dtype != torch.float16 or t.dim() != 2 or t.stride(1) != 1:
                 raise _lib.ChirrupAmdError(f"{name}: expected a GPU fp16 matrix with unit inner stride")
-        if tuple(x.shape) != (M, K) or w.shape[1] != K or x.stride(0) != x0.stride(0) or w.stride(0) != w0.stride(0) \
-                or tuple(out.shape) != (M, w.shape[0]):
-            raise _lib.ChirrupAmdError("skinny_group: problems must share M, K and the row strides of x and weight")
+        N, wptr, ldw, w_tiled = _weight_args(w, K)
+        if not w_tiled:                          # row-major weights share one row stride; tiled ones have none
+            ldw0 = ldw if ldw0 is None else ldw0
+            if ldw != ldw0:
+                raise _lib.ChirrupAmdError("skinny_group: row-major weights must share their row stride")
+        if tuple(x.shape) != (M, K) or x.stride(0) != x0.stride(0) or tuple(out.shape) != (M, N):
+            raise _lib.ChirrupAmdError("skinny_group: problems must share M, K and the row stride of x")
         if bias is not None:
-            _chk16("bias", bias, w.shape[0])
-        arr[i] = _GemmProblem(x.data_ptr(), w.data_ptr(), out.data_ptr(), _ptr(bias) or None, w.shape[0], out.stride(0), _GROUP_ACTS[act])
+            _chk16("bias", bias, N)
+        arr[i] = _GemmProblem(x.data_ptr(), wptr, out.data_ptr(), _ptr(bias) or None, N, out.stride(0), _GROUP_ACTS[act], w_tiled)
     L = _lib.load()
     nbytes = L.skinny_gemm_group_workspace_bytes(len(problems), ctypes.addressof(arr), M, splits)
     ws = _workspace(nbytes + 256, x0.device)
     base = (ws.data_ptr() + 255) // 256 * 256
-    rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), w0.stride(0), splits, base, _stream())
+    rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), ldw0 if ldw0 is not None else K, splits,
+                                 base, _stream())
     _lib.check(rc, "skinny_gemm_f16_group")
 
 
@@ -367,14 +401,14 @@ def skinny_linear_partial(x, weight, splits: int, partials):
     """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
     [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""
     M, K = x.shape
-    N = weight.shape[0]
+    N, wptr, ldw, w_tiled = _weight_args(weight, K)
     if partials.dtype != torch.float32 or not partials.is_contiguous():
         raise _lib.ChirrupAmdError("partials: expected contiguous fp32")
     L = _lib.load()
     want = L.skinny_gemm_workspace_bytes(M, N, K, splits) or M * N * 4
     if partials.numel() * 4 < want:
         raise _lib.ChirrupAmdError("partials buffer too small")
-    rc = L.skinny_gemm_f16_partial(M, N, K, x.data_ptr(), x.stride(0), weight.data_ptr(), weight.stride(0), splits,
+    rc = L.skinny_gemm_f16_partial(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, splits,
                                    partials.data_ptr(), _stream())
     if rc <= 0:
         raise _lib.ChirrupAmdError(f"skinny_gemm_f16_partial: {rc}")

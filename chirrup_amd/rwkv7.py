@@ -85,7 +85,8 @@ class _Layer:
 
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
-                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows")
+                 "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows",
+                 "rkv_t", "O_t", "f_K_t", "f_V_t")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -133,6 +134,18 @@ class _Layer:
                 setattr(self, "v" + sfx, z[a + "a" + sfx])
         self.lbias = torch.stack([self.v0, self.w0, self.a0, torch.zeros_like(self.a0)]).view(4, 1, C).contiguous()
 
+    def tile_for_ring(self):
+        """Second copies of the matrices the ring GEMM streams at decode batch sizes (R/K/V, att.output, ffn.key,
+        ffn.value), in its tile-image layout: each 128-row x 64-k tile is 16 KiB of consecutive bytes, so a 1-KiB
+        LDS-DMA instruction reads consecutive memory (-3 ... -4.5 us per launch at 7.2B / bsz 200).
+        The row-major originals stay: the prefill path multiplies them through the library.  +12*C^2*2 B per layer
+        (12.9 GB for 7.2B) of the 288 GB."""
+        ok = lambda t: t is not None and t.shape[0] % 128 == 0 and t.shape[1] % 64 == 0
+        self.rkv_t = [ops.tile_weight(self.rkv[j]) for j in range(3)] if ok(self.rkv[0]) else None
+        self.O_t = ops.tile_weight(self.O) if ok(self.O) else None
+        self.f_K_t = ops.tile_weight(self.f_K) if ok(self.f_K) else None
+        self.f_V_t = ops.tile_weight(self.f_V.t()) if (self.f_V is not None and ok(self.f_V.t())) else None
+
     def quantize_ffn(self, z, i):
         """mm8 (w8a16) channel-mix: quantise ffn.key / ffn.value like the reference's quantize_weight
         (scripts/test_mm8/benchmark.py:54-85, matrices named at :447-452) and drop the fp16 copies.
@@ -153,8 +166,9 @@ class RWKV_x070:
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
                  fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16,
-                 sparse_bsz1: bool = False):
+                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 4096):
         self.args = args
+        self.tiled_weights = bool(tiled_weights)     # second, tile-image copies of the ring GEMM's matrices (_Layer.tile_for_ring)
         args.head_size = HEAD_SIZE
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
@@ -178,7 +192,7 @@ class RWKV_x070:
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_rows = 33                        # ... and from this many rows up (7.2B: equal at 32, -8 % at 64, slower at 16)
-        self.skinny_min_embd = 4096                      # ... where it beats the library (measured at C = 4096)
+        self.skinny_min_embd = skinny_min_embd           # ... where it beats the library (measured at C = 4096)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
@@ -200,6 +214,9 @@ class RWKV_x070:
                 if ffn_dtype == torch.int8:
                     lw.quantize_ffn(self.z, i)
                 lw.f_V_rows = lw.f_V.contiguous() if self.sparse_bsz1 else None
+                lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = None
+                if self.tiled_weights and self.n_embd >= self.skinny_min_embd:
+                    lw.tile_for_ring()
             torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ reference surface
@@ -416,7 +433,8 @@ class RWKV_x070:
                 # LoRA up-projections, all on this stream: no cross-stream edges (they cost ~19 us per layer)
                 rkv = new(3, rows, C)
                 hid = new(4 - p0, rows, lw.lora1.shape[1])         # columns past a problem's rank are never read
-                probs = [(mixed[j], lw.rkv[j], rkv[j], None, None) for j in range(3)]
+                wr = lw.rkv_t if lw.rkv_t is not None else lw.rkv
+                probs = [(mixed[j], wr[j], rkv[j], None, None) for j in range(3)]
                 for j in range(p0, 4):
                     kj = lw.lora_k[j]
                     probs.append((mixed[2 + j], lw.lora1[j, :kj], hid[j - p0, :, :kj], None, ("tanh" if j == 1 else ("sigmoid" if j == 3 else None))))
@@ -463,7 +481,7 @@ class RWKV_x070:
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
             if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
-                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O, 8, pbuf_o)   # reduce folded into the LN below
+                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, 8, pbuf_o)   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
                                lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
             else:
@@ -477,7 +495,7 @@ class RWKV_x070:
                 delta = ops.mm8t_linear(kf, *lw.f_V8).view(B, T, C)
             else:
                 if use_parts and self.skinny_ffn_key and rows >= self.skinny_wide_rows:
-                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K, act=1, splits=2)
+                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=2)
                 else:
                     kf = F.linear(kin[0], lw.f_K)
                     ops.relu_sq_(kf)
@@ -487,7 +505,7 @@ class RWKV_x070:
                     # K = 4C >> N = C at decode batch sizes: the hand-written LDS-DMA ring GEMM streams this
                     # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200);
                     # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
-                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V.t(), 8, pbuf), None
+                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), 8, pbuf), None
                 else:
                     delta = kf @ lw.f_V
         if dparts is not None and (T > 1 and not full_output):

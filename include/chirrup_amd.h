@@ -164,7 +164,7 @@ int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
 /* As skinny_gemm_f16 without bias/activation, but leaves the `splits` binary32 partial results
  * [splits][M][N] in `partials` for the consumer to sum (see rwkv7_add_ln_mix). Returns the split count used
  * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
-int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int splits,
+int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, int splits,
                             float *partials, void *stream);
 /* Z independent skinny GEMMs in ONE launch (RWKV-7's receptance/key/value projections, Albatross/rwkv7.py:603-605,
  * and its four LoRA pairs, :626-637): Y[z] = act(X[z] . W[z]^T + bias[z]).  Problem z's operands start z * (their
@@ -193,6 +193,7 @@ typedef struct {
     void *y;           /* [M][ldy] binary16 */
     const void *bias;  /* [n] binary16 or NULL */
     int n, ldy, act;
+    int w_tiled;       /* w is in the tile-image layout (skinny_tile_weight); needs n % 128 == 0 */
 } chirrup_gemm_problem;
 int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int splits);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
@@ -200,8 +201,14 @@ int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M
 /* Kernel variant (A/B switch): 0 register-staged; 1 both operands through one LDS-DMA ring loaded by the compute
  * waves; 2 per-wave x / W loader roles; 3 (default) four dedicated loader waves (see skinny_gemm.hip). */
 void skinny_gemm_select(int mode);
-int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, const void *bias,
+int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
                     void *Y, int ldy, int act, int splits, void *workspace, void *stream);
+/* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
+ * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
+ * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight
+ * 128-B pieces of eight rows K*2 bytes apart.  Wt: N*K elements, must not overlap W.  The row-major matrix is still
+ * what every other consumer (library GEMMs of the prefill path) needs. */
+int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream);
 
 /*
  * mm8 (w8a16) on the matrix cores: same quantisation and result as mm8_seq, but the uint8 weights

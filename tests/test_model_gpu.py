@@ -221,8 +221,9 @@ def test_skinny_ffn_value_with_reduce_folded_into_next_ln(B, T):
     d = np.load(os.path.join(G, "model_L2_C128.npz"))
     zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
     args = lambda: types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
-    ma, mb = RWKV_x070(args(), state_dict=zd, device="cuda:0"), RWKV_x070(args(), state_dict=zd, device="cuda:0")
-    ma.skinny_min_embd = 0            # force the path on this tiny model (production: C >= 4096)
+    ma = RWKV_x070(args(), state_dict=zd, device="cuda:0", skinny_min_embd=0)   # force the path on this tiny model (production: C >= 4096)
+    mb = RWKV_x070(args(), state_dict=zd, device="cuda:0")
+    assert ma._layers[0].rkv_t is not None and ma._layers[1].f_V_t is not None     # incl. the tile-image weight copies
     mb.skinny_ffn_value = False
     rng = np.random.default_rng(B)
     toks = rng.integers(1, 320, size=(B, T)).tolist()
@@ -254,9 +255,9 @@ def test_decode_batch_path_with_hand_written_gemms_vs_oracle(oracle):
     zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
     z_np = M.prepare_weights({k[2:]: d[k] for k in d.files if k.startswith("w:")})
     args = lambda: types.SimpleNamespace(vocab_size=320, head_size=64, MODEL_NAME="unused")
-    hw, lib = RWKV_x070(args(), state_dict=zd, device="cuda:0"), RWKV_x070(args(), state_dict=zd, device="cuda:0")
-    hw.skinny_min_embd = 0
-    lib.skinny_min_embd = 10 ** 9
+    hw = RWKV_x070(args(), state_dict=zd, device="cuda:0", skinny_min_embd=0)
+    lib = RWKV_x070(args(), state_dict=zd, device="cuda:0", skinny_min_embd=10 ** 9)
+    assert hw._layers[0].O_t is not None and lib._layers[0].O_t is None
     B = 200
     rng = np.random.default_rng(7)
     st_np = [t.cpu().numpy().copy() for t in hw.generate_zero_state(B)]

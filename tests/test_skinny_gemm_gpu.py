@@ -168,3 +168,39 @@ def test_grouped_launch_of_unequal_problems():
         got = hid[j, :, :ranks[j]].double()
         assert bool(((got - want).abs() <= 2e-3 * want.abs().clamp_min(1.0)).all()), j
         assert float(hid[j, :, ranks[j]:].abs().max()) == 0.0 if ranks[j] < 512 else True      # nothing written past N
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 4096, 4096), (200, 4096, 16384), (33, 128, 64), (130, 512, 128)])
+def test_tile_image_weight_layout_gives_the_same_bits(M, N, K):
+    """skinny_tile_weight re-lays W as consecutive 16-KiB tile images; every entry point must give bit-identical
+    results with the tiled copy (same fragments, same accumulation order -- only the addresses of the loads differ)."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(N + K)
+    x = torch.randn(M, K, device="cuda").half()
+    wbig = torch.zeros(N, K + 64, device="cuda", dtype=torch.float16)
+    wbig[:, :K] = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    w = wbig[:, :K]                                              # row-strided source
+    wt = ops.tile_weight(w)
+    assert wt.shape == (N, K) and wt.data.numel() == N * K
+    # the packing itself: tile (g, b), chunk c holds row g*128 + (c >> 3), logical chunk (c & 7) ^ ((row >> 1) & 7)
+    img = wt.data.view(N // 128, K // 64, 128, 8, 8)
+    nr = torch.arange(128, device="cuda")
+    lc = torch.arange(8, device="cuda").view(1, 8) ^ ((nr >> 1) & 7).view(128, 1)
+    want = w.contiguous().view(N // 128, 128, K // 64, 8, 8).permute(0, 2, 1, 3, 4)
+    want = torch.gather(want, 3, lc.view(1, 1, 128, 8, 1).expand(N // 128, K // 64, 128, 8, 8))
+    assert torch.equal(img, want)
+    b = torch.randn(N, device="cuda").half()
+    for splits, act in ((1, 0), (2, 1), (0, 0)):
+        assert torch.equal(ops.skinny_linear(x, w, b, act=act, splits=splits), ops.skinny_linear(x, wt, b, act=act, splits=splits))
+    pa, pb = torch.empty(8, M, N, device="cuda"), torch.empty(8, M, N, device="cuda")
+    a_, b_ = ops.skinny_linear_partial(x, w, 8, pa), ops.skinny_linear_partial(x, wt, 8, pb)
+    assert a_.shape == b_.shape and torch.equal(a_, b_)
+    ya, yb = torch.empty(M, N, device="cuda", dtype=torch.float16), torch.empty(M, N, device="cuda", dtype=torch.float16)
+    sbig = torch.zeros(64, K + 64, device="cuda", dtype=torch.float16)      # same row stride as w (one ldw per launch)
+    sbig[:, :K] = (torch.randn(64, K, device="cuda") / K ** 0.5).half()
+    small = sbig[:, :K]
+    sa, sb = torch.empty(M, 64, device="cuda", dtype=torch.float16), torch.empty(M, 64, device="cuda", dtype=torch.float16)
+    ops.skinny_group([(x, w, ya, None, None), (x, small, sa, None, "tanh")], splits=1)
+    ops.skinny_group([(x, wt, yb, None, None), (x, small, sb, None, "tanh")], splits=1)      # tiled and row-major problems mixed
+    assert torch.equal(ya, yb) and torch.equal(sa, sb)

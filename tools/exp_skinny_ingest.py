@@ -37,7 +37,7 @@ for name, N, K, s in [("att CxC", 4096, 4096, 8), ("ffn.key", 16384, 4096, 2), (
         def go():
             st = vp(torch.cuda.current_stream().cuda_stream)
             for W in Ws:
-                rc = L.skinny_gemm_f16_partial(M, N, K, vp(x.data_ptr()), K, vp(W.data_ptr()), ctypes.c_int64(K), s, vp(part.data_ptr()), st)
+                rc = L.skinny_gemm_f16_partial(M, N, K, vp(x.data_ptr()), K, vp(W.data_ptr()), ctypes.c_int64(K), 0, s, vp(part.data_ptr()), st)
                 assert rc == s, rc
         line += f"  {tag} {timeit(go) / nw * 1e3:6.1f} us"
     print(line, flush=True)
