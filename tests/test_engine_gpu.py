@@ -33,14 +33,15 @@ def test_engine_from_checkpoint_file_matches_direct_decode(tmp_path):
         ids = tok.encode(text)
         st = ref.generate_zero_state(1)
         lg = ref.forward_seq_batch_seperate([ids], st)
-        out, margin = [], 1e9
-        for _ in range(n_new):
+        out, safe = [], 0                    # safe = ids before the first step whose top-2 margin is within fp16 noise
+        for i in range(n_new):
             top2 = torch.topk(lg.float(), 2, dim=-1).values[0]
-            margin = min(margin, float(top2[0] - top2[1]))
+            if float(top2[0] - top2[1]) >= 0.02 and safe == i:
+                safe = i + 1
             t = int(lg.float().argmax(-1))
             out.append(t)
             lg = ref.forward_seq_batch_seperate([[t]], st)
-        return out, margin
+        return out, safe
 
     async def main():
         eng = AsyncEngineCore()
@@ -55,14 +56,13 @@ def test_engine_from_checkpoint_file_matches_direct_decode(tmp_path):
         return streams
 
     streams = asyncio.run(main())
+    checked = 0
     for p, got in zip(prompts, streams):
-        want, margin = solo(p)
+        want, safe = solo(p)
+        checked += safe
         ids = [g[0] for g in got]
         assert len(ids) == n_new
-        if margin >= 0.02:                      # ids are defined where the arg-max is clear of fp16 noise
-            assert ids == want, (p, margin)
-        else:
-            assert ids[0] == want[0]
+        assert ids[:safe] == want[:safe], (p, safe)     # ids are defined where the arg-max is clear of fp16 noise
         def text_of(i):                      # the tiny model's vocab (320) is larger than the vocabulary file (164 ids)
             try:
                 return tok.decode([i], utf8_errors="ignore")
@@ -70,3 +70,4 @@ def test_engine_from_checkpoint_file_matches_direct_decode(tmp_path):
                 return ""
 
         assert [g[1] for g in got] == [text_of(i) for i in ids]
+    assert checked >= 3          # the comparison must not be vacuous
