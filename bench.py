@@ -49,19 +49,22 @@ def parse():
     p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
     p.add_argument("--skinny-min-rows", type=int, default=None, help="lower row bound of the hand-written GEMM path, A/B only")
     p.add_argument("--skinny-att-out", type=int, default=None, help="1/0: att.output through the hand-written GEMM, A/B only")
+    p.add_argument("--skinny-wide-rows", type=int, default=None, help="row bound from which att.output / ffn.key use the hand-written GEMM, A/B only")
+    p.add_argument("--skinny-min-embd", type=int, default=None, help="smallest n_embd that uses the hand-written GEMM path, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     return p.parse_args()
 
 
-def build_model(name, device, fused, mm8=False, tiled=True):
+def build_model(name, device, fused, mm8=False, tiled=True, min_embd=None):
     from chirrup_amd.rwkv7 import RWKV_x070, model_args
     from chirrup_amd.synth import CONFIGS, make_state_dict
 
     L, C = CONFIGS[name]
     zd = make_state_dict(L, C, 65536, seed=42, device=device)      # random-init weights of the architecture
     m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused,
-                  ffn_dtype=torch.int8 if mm8 else torch.float16, tiled_weights=tiled)
+                  ffn_dtype=torch.int8 if mm8 else torch.float16, tiled_weights=tiled,
+                  **({} if min_embd is None else {"skinny_min_embd": min_embd}))
     del zd
     torch.cuda.empty_cache()
     return m
@@ -223,7 +226,7 @@ def main():
 
     L, C = CONFIGS[a.model]
     B = a.bsz
-    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled)
+    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
     if a.gemm_mode is not None:
         from chirrup_amd import lib
         lib.load().skinny_gemm_select(a.gemm_mode)
@@ -231,6 +234,8 @@ def main():
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:
         model.skinny_rkv = bool(a.skinny_rkv)
+    if a.skinny_wide_rows is not None:
+        model.skinny_wide_rows = a.skinny_wide_rows
     if a.skinny_att_out is not None:
         model.skinny_att_out = bool(a.skinny_att_out)
     if a.skinny_min_rows is not None:

@@ -166,7 +166,7 @@ class RWKV_x070:
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
                  fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16,
-                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 4096):
+                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 0):
         self.args = args
         self.tiled_weights = bool(tiled_weights)     # second, tile-image copies of the ring GEMM's matrices (_Layer.tile_for_ring)
         args.head_size = HEAD_SIZE
@@ -191,12 +191,12 @@ class RWKV_x070:
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
-        self.skinny_min_rows = 33                        # ... and from this many rows up (7.2B: equal at 32, -8 % at 64, slower at 16)
-        self.skinny_min_embd = skinny_min_embd           # ... where it beats the library (measured at C = 4096)
+        self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
+        self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
-        self.skinny_wide_rows = 129                      # att.output / ffn.key join the hand-written path from here (M = 64: library faster)
+        self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
         self.skinny_att_out = True                       # att.output through the ring kernel, its reduce folded into LN2
         self.skinny_ffn_key = True                       # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         self.ffn_dtype = ffn_dtype
