@@ -23,8 +23,8 @@ TorchScript module: the per-layer work is organised around the HIP kernels of th
     residual add + LN2 + token-shift + lerp    ->  one kernel
     head                                       ->  hipBLASLt through torch
 
-(that is the decode-batch regime, 33..256 token rows at C >= 4096; outside it -- a single stream, prefill chunks,
-small models -- the projections are library GEMMs and the LoRA chain overlaps R/K/V on a side stream)
+(that is the decode regime, 1..256 token rows; prefill chunks of more rows run the projections as library GEMMs with
+the LoRA chain beside R/K/V on a side stream)
 
 and the whole decode step can be captured in a HIP graph (`capture_decode_graph`).  With
 ``fused=False`` the same arithmetic runs as plain torch ops (one rounding to fp16 per op, exactly
