@@ -1,5 +1,5 @@
 // Skinny-M MFMA GEMMs for the decode step:  Y[M][N] = X[M][K] . W[N][K]^T   (M <= 256 token rows)
-// with binary16 or uint8 (mm8) weights, binary32 accumulation.  One RWKV-7 layer at 33..256 rows runs five launches of
+// with binary16 or uint8 (mm8) weights, binary32 accumulation.  One RWKV-7 layer at 1..256 token rows runs five launches of
 // the ring kernel below: R/K/V + the four LoRA down-projections (grouped), the four LoRA up-projections (batched, per-
 // problem reduction length), att.output, ffn.key, ffn.value (DESIGN.md sections 4-5 have the measurements).
 //
