@@ -353,8 +353,9 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
                 const int lc = (g & 3) ^ ((nr >> 2) & 3);
                 int n = n_base + nr;
                 n = n < Np ? n : Np - 1;
-                __builtin_amdgcn_global_load_lds((gptr_t)(static_cast<const uint8_t *>(Wv) + (int64_t)n * ldw + k0 + lc * 16),
-                                                 (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
+                const uint8_t *src = w_tiled ? static_cast<const uint8_t *>(Wv) + ((int64_t)ngroup * (K / kKB) + k0 / kKB) * (kBN * kKB) + g * 16
+                                             : static_cast<const uint8_t *>(Wv) + (int64_t)n * ldw + k0 + lc * 16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
             } else {
                 const int nr = g >> 3;
                 const int lc = (g & 7) ^ ((nr >> 1) & 7);
@@ -685,7 +686,30 @@ __global__ __launch_bounds__(256) void tile_weight_kernel(const int N, const int
     const int nr = g >> 3, lc = (g & 7) ^ ((nr >> 1) & 7);
     *reinterpret_cast<f16x8 *>(Wt + c * 8) = *reinterpret_cast<const f16x8 *>(W + ((int64_t)ng * kBN + nr) * ldw + kb * kKB + lc * 8);
 }
+// uint8 form: tile (g, b) = 512 chunks of 16 B; row nr = c >> 2 at chunk position c & 3 holds logical chunk (c & 3) ^ ((nr >> 2) & 3)
+__global__ __launch_bounds__(256) void tile_weight_u8_kernel(const int N, const int K, const uint8_t *__restrict__ W, const int64_t ldw,
+                                                             uint8_t *__restrict__ Wt) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * K / 16;
+    if (c >= total) return;
+    const int g = (int)(c & 511);
+    const int64_t tile = c >> 9;
+    const int kb = (int)(tile % (K / kKB)), ng = (int)(tile / (K / kKB));
+    const int nr = g >> 2, lc = (g & 3) ^ ((nr >> 2) & 3);
+    *reinterpret_cast<u32x4 *>(Wt + c * 16) = *reinterpret_cast<const u32x4 *>(W + ((int64_t)ng * kBN + nr) * ldw + kb * kKB + lc * 16);
+}
 }  // namespace
+
+// The same for the uint8 (mm8) weights wT [M_out][N_in] of mm8t_seq (w_tiled = 1 there): 8-KiB tile images.
+extern "C" int skinny_tile_weight_u8(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream) {
+    if (N <= 0 || K <= 0 || (N % kBN) || (K % kKB) || ldw < K || (ldw & 15)) return CHIRRUP_E_SHAPE;
+    if (!W || !Wt) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Wt) & 15)) return CHIRRUP_E_ALIGN;
+    const int64_t total = (int64_t)N * K / 16;
+    hipLaunchKernelGGL(tile_weight_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, K, static_cast<const uint8_t *>(W), ldw, static_cast<uint8_t *>(Wt));
+    return (int)hipGetLastError();
+}
 
 // Re-lay a binary16 weight matrix W [N][K] (N % 128 == 0, K % 64 == 0) as contiguous 16-KiB tile images for the ring
 // kernel (w_tiled = 1 in the GEMM calls).  Wt needs N*K elements; W and Wt must not overlap.
@@ -883,9 +907,10 @@ extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) 
     return b;
 }
 
-extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,
+extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
                         const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
                         int splits, void *workspace, void *stream) {
+    if (w_tiled && ((M_out % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
     if (B <= 0 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
         y_stride < M_out || (x_stride & 7) || (w_stride & 15) || (y_stride & 3))
         return CHIRRUP_E_SHAPE;
@@ -913,8 +938,10 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         const int MT = (bn + 31) / 32;
         const dim3 grid((M_out + kBN - 1) / kBN, s);
         const size_t lds = (size_t)2 * MT * 32 * 128;
+        BatchStrides bs{};
+        bs.tiled = w_tiled ? 1 : 0;
         int rc = g_mode ? launch_ring<true, EPI_PARTIAL>(MT, grid, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb,
-                                                         y_stride, nullptr, part)
+                                                         y_stride, nullptr, part, bs)
                         : launch<true>(MT, true, grid, lds, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb, y_stride,
                                        nullptr, part);
         if (rc) return rc;

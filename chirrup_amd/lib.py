@@ -51,7 +51,8 @@ SIGNATURES = {
     "skinny_tile_weight": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
-    "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "skinny_tile_weight_u8": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
 }
 
 

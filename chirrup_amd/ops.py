@@ -415,11 +415,25 @@ def skinny_linear_partial(x, weight, splits: int, partials):
     return partials.view(-1)[: rc * M * N].view(rc, M, N)
 
 
-def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None):
-    """mm8 with K-contiguous uint8 weights wT [M_out, N_in] (see include/chirrup_amd.h: mm8t_seq)."""
+def tile_weight_u8(wT: torch.Tensor) -> torch.Tensor:
+    """uint8 wT [M_out, N_in] (M_out % 128 == 0, N_in % 64 == 0) -> a NEW flat tensor of 8-KiB tile images for mm8t_linear(tiled=True)."""
+    if wT.dim() != 2 or not wT.is_cuda or wT.dtype != torch.uint8 or wT.stride(1) != 1:
+        raise _lib.ChirrupAmdError("tile_weight_u8: expected a GPU uint8 matrix with unit inner stride")
+    out = torch.empty((wT.shape[0] * wT.shape[1],), dtype=torch.uint8, device=wT.device)
+    rc = _lib.load().skinny_tile_weight_u8(wT.shape[0], wT.shape[1], wT.data_ptr(), wT.stride(0), out.data_ptr(), _stream())
+    _lib.check(rc, "skinny_tile_weight_u8")
+    return out
+
+
+def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None, tiled: bool = False):
+    """mm8 with K-contiguous uint8 weights wT [M_out, N_in] (see include/chirrup_amd.h: mm8t_seq); tiled=True: wT is
+    the flat tile-image form of tile_weight_u8 (M_out is then taken from mx)."""
     B, N = x.shape
-    M = wT.shape[0]
-    if not wT.is_cuda or wT.dtype != torch.uint8 or wT.shape[1] != N or wT.stride(1) != 1:
+    M = mx.shape[0] if tiled else wT.shape[0]
+    if tiled:
+        if not wT.is_cuda or wT.dtype != torch.uint8 or wT.numel() != M * N or not wT.is_contiguous():
+            raise _lib.ChirrupAmdError("wT: expected the flat uint8 tile-image form of [M_out, N_in]")
+    elif not wT.is_cuda or wT.dtype != torch.uint8 or wT.shape[1] != N or wT.stride(1) != 1:
         raise _lib.ChirrupAmdError("wT: expected GPU uint8 [M_out, N_in] with unit inner stride")
     if not x.is_cuda or x.dtype != torch.float16 or x.stride(1) != 1:
         raise _lib.ChirrupAmdError("x: expected GPU fp16 with unit inner stride")
@@ -429,7 +443,7 @@ def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None):
     L = _lib.load()
     ws = _workspace(L.mm8t_workspace_bytes(B, N, M, splits) + 256, x.device)
     base = (ws.data_ptr() + 255) // 256 * 256
-    rc = L.mm8t_seq(B, N, M, x.data_ptr(), x.stride(0), wT.data_ptr(), wT.stride(0), mx.data_ptr(), rx.data_ptr(),
+    rc = L.mm8t_seq(B, N, M, x.data_ptr(), x.stride(0), wT.data_ptr(), N if tiled else wT.stride(0), int(tiled), mx.data_ptr(), rx.data_ptr(),
                     my.data_ptr(), ry.data_ptr(), out.data_ptr(), out.stride(0), act, splits, base, _stream())
     _lib.check(rc, "mm8t_seq")
     return out

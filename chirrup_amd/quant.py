@@ -41,3 +41,14 @@ def quantize_linear(weight_out_in: torch.Tensor) -> Mm8Weight:
     the matrix in the orientation it multiplies with, w = W.T [N_in, M_out]."""
     q, mx, rx, my, ry = quantize_weight(weight_out_in.t())
     return Mm8Weight(q.t().contiguous(), mx, rx, my.reshape(-1).contiguous(), ry.reshape(-1).contiguous())
+
+
+def untile_u8(flat: torch.Tensor, m_out: int, n_in: int) -> torch.Tensor:
+    """Inverse of ops.tile_weight_u8 (inspection / tests): flat tile images -> uint8 [m_out, n_in] row-major.
+    Tile (g, b) = 512 chunks of 16 B; row nr = c >> 2 at chunk position c & 3 holds logical chunk (c & 3) ^ ((nr >> 2) & 3)."""
+    img = flat.view(m_out // 128, n_in // 64, 128, 4, 16)
+    nr = torch.arange(128, device=flat.device)
+    pos = torch.arange(4, device=flat.device).view(1, 4) ^ ((nr >> 2) & 3).view(128, 1)     # position of logical chunk lc in row nr
+    rows = torch.gather(img, 3, pos.view(1, 1, 128, 4, 1).expand(m_out // 128, n_in // 64, 128, 4, 16))
+    return rows.permute(0, 2, 1, 3, 4).reshape(m_out, n_in).contiguous()
+

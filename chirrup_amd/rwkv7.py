@@ -86,7 +86,7 @@ class _Layer:
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
                  "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows",
-                 "rkv_t", "O_t", "f_K_t", "f_V_t")
+                 "rkv_t", "O_t", "f_K_t", "f_V_t", "f8_tiled")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -146,7 +146,7 @@ class _Layer:
         self.f_K_t = ops.tile_weight(self.f_K) if ok(self.f_K) else None
         self.f_V_t = ops.tile_weight(self.f_V.t()) if (self.f_V is not None and ok(self.f_V.t())) else None
 
-    def quantize_ffn(self, z, i):
+    def quantize_ffn(self, z, i, tile: bool = False):
         """mm8 (w8a16) channel-mix: quantise ffn.key / ffn.value like the reference's quantize_weight
         (scripts/test_mm8/benchmark.py:54-85, matrices named at :447-452) and drop the fp16 copies.
         z keeps '<key>.mm8' -> Mm8Weight instead of the fp16 tensor."""
@@ -155,6 +155,12 @@ class _Layer:
         f = f"blocks.{i}.ffn."
         self.f_K8 = quantize_linear(self.f_K)                 # Linear weight [4C, C]
         self.f_V8 = quantize_linear(self.f_V.t())             # f_V is the [4C, C] view of the [C, 4C] Linear weight
+        self.f8_tiled = False
+        if tile and all(w.qT.shape[0] % 128 == 0 and w.qT.shape[1] % 64 == 0 for w in (self.f_K8, self.f_V8)):
+            # the uint8 matrices are only ever read by the MFMA ring kernel: keep them in its tile-image layout ONLY
+            self.f_K8 = self.f_K8._replace(qT=ops.tile_weight_u8(self.f_K8.qT))
+            self.f_V8 = self.f_V8._replace(qT=ops.tile_weight_u8(self.f_V8.qT))
+            self.f8_tiled = True
         z[f + "key.weight.mm8"], z[f + "value.weight.mm8"] = self.f_K8, self.f_V8
         del z[f + "key.weight"], z[f + "value.weight"]
         self.f_K = self.f_V = None
@@ -212,7 +218,7 @@ class RWKV_x070:
             for i, lw in enumerate(self._layers):
                 lw.pack_for_fused(self.z, i)
                 if ffn_dtype == torch.int8:
-                    lw.quantize_ffn(self.z, i)
+                    lw.quantize_ffn(self.z, i, tile=self.tiled_weights)
                 lw.f_V_rows = lw.f_V.contiguous() if self.sparse_bsz1 else None
                 lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = None
                 if self.tiled_weights and self.n_embd >= self.skinny_min_embd:
@@ -491,8 +497,8 @@ class RWKV_x070:
             if T > 1:
                 commit_carry(prev)
             if self.ffn_dtype == torch.int8:        # mm8 on the matrix cores, relu^2 fused into the epilogue
-                kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1)
-                delta = ops.mm8t_linear(kf, *lw.f_V8).view(B, T, C)
+                kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)
+                delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)
             else:
                 if use_parts and self.skinny_ffn_key and rows >= self.skinny_wide_rows:
                     kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=2)

@@ -209,6 +209,8 @@ int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, 
  * 128-B pieces of eight rows K*2 bytes apart.  Wt: N*K elements, must not overlap W.  The row-major matrix is still
  * what every other consumer (library GEMMs of the prefill path) needs. */
 int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream);
+/* The same for mm8t_seq's uint8 weights wT [M_out][N_in] (N = M_out, K = N_in): 8-KiB tile images, w_tiled = 1 there. */
+int skinny_tile_weight_u8(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream);
 
 /*
  * mm8 (w8a16) on the matrix cores: same quantisation and result as mm8_seq, but the uint8 weights
@@ -220,7 +222,7 @@ int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void 
  * rows (chunked prefill) are processed 256 at a time, each block re-streaming the weights.
  */
 int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits);
-int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride,
+int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
              const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
              int splits, void *workspace, void *stream);
 

@@ -145,7 +145,10 @@ def test_mm8_channel_mix_model_vs_oracle(oracle):
     m8 = RWKV_x070(args(), state_dict=zd, device="cuda:0", ffn_dtype=torch.int8)
     m16 = RWKV_x070(args(), state_dict=zd, device="cuda:0")
     assert "blocks.0.ffn.key.weight" not in m8.z and m8.z["blocks.0.ffn.key.weight.mm8"].qT.dtype == torch.uint8
-    assert np.array_equal(m8.z["blocks.1.ffn.value.weight.mm8"].qT.t().cpu().numpy(), mm8[1][1][0])   # same bytes as the oracle's
+    from chirrup_amd.quant import untile_u8
+    assert m8._layers[1].f8_tiled                      # the u8 matrices live in the ring kernel's tile-image layout only
+    qT = untile_u8(m8.z["blocks.1.ffn.value.weight.mm8"].qT, 128, 512)
+    assert np.array_equal(qT.t().cpu().numpy(), mm8[1][1][0])   # same bytes as the oracle's
     for tag in ("b3t1", "b3t5"):
         st_np = [d[f"{tag}:{n}_in"].copy() for n in ("s0", "s1", "s2")]
         lg_np = M.forward_seq_batch(z_np, d[f"{tag}:tokens"].tolist(), st_np, 2, mm8=mm8)

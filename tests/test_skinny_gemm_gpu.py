@@ -204,3 +204,20 @@ def test_tile_image_weight_layout_gives_the_same_bits(M, N, K):
     ops.skinny_group([(x, w, ya, None, None), (x, small, sa, None, "tanh")], splits=1)
     ops.skinny_group([(x, wt, yb, None, None), (x, small, sb, None, "tanh")], splits=1)      # tiled and row-major problems mixed
     assert torch.equal(ya, yb) and torch.equal(sa, sb)
+
+
+def test_u8_tile_image_layout_gives_the_same_bits(oracle):
+    from chirrup_amd import ops
+    from chirrup_amd.quant import untile_u8
+
+    rng = np.random.default_rng(3)
+    B, N, M = 200, 512, 256
+    x = torch.from_numpy(rng.standard_normal((B, N)).astype(np.float16)).cuda()
+    w16 = (rng.standard_normal((N, M)) / np.sqrt(N)).astype(np.float16)
+    q, mx, rx, my, ry = M_.quantize_weight(w16)
+    qT = torch.from_numpy(np.ascontiguousarray(q.T)).cuda()
+    args = [torch.from_numpy(a.reshape(-1)).cuda() for a in (mx, rx, my, ry)]
+    flat = ops.tile_weight_u8(qT)
+    assert torch.equal(untile_u8(flat, M, N), qT)
+    for act in (0, 1):
+        assert torch.equal(ops.mm8t_linear(x, qT, *args, act=act), ops.mm8t_linear(x, flat, *args, act=act, tiled=True))
