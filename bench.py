@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--skinny-att-out", type=int, default=None, help="1/0: att.output through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-wide-rows", type=int, default=None, help="row bound from which att.output / ffn.key use the hand-written GEMM, A/B only")
     p.add_argument("--skinny-min-embd", type=int, default=None, help="smallest n_embd that uses the hand-written GEMM path, A/B only")
+    p.add_argument("--skinny-head", type=int, default=None, help="1/0: head GEMM through the hand-written kernel, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     return p.parse_args()
@@ -234,6 +235,8 @@ def main():
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:
         model.skinny_rkv = bool(a.skinny_rkv)
+    if a.skinny_head is not None:
+        model.skinny_head = bool(a.skinny_head)
     if a.skinny_wide_rows is not None:
         model.skinny_wide_rows = a.skinny_wide_rows
     if a.skinny_att_out is not None:
