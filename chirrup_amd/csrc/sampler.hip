@@ -311,10 +311,12 @@ extern "C" int rwkv7_sample_topp(int n_rows, int V, const void *logits, const in
     if (!logits || !rows || !temperature || !top_p || !top_k || !uniform || !ids) return CHIRRUP_E_NULL;
     if (reinterpret_cast<uintptr_t>(logits) & 15) return CHIRRUP_E_ALIGN;
     const size_t lds = ((size_t)V * 2 + 15) / 16 * 16 + (size_t)kHistReplicas * 256 * 8 + 16 * 4 + 8 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[32] = {};            // per device: one engine process may drive several GPUs
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!attr_set[dev & 31]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sample_topp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[dev & 31] = true;
     }
     hipLaunchKernelGGL(sample_topp_kernel, dim3((unsigned)n_rows), dim3(kSampThreads), lds, static_cast<hipStream_t>(stream), V,
                        static_cast<const f16 *>(logits), rows, static_cast<const f16 *>(temperature),

@@ -639,11 +639,13 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
 #define GO(MTV)                                                                                                           \
     do {                                                                                                                  \
         auto kern = skinny_gemm_ring_kernel<MTV, W8, EPI, XD, WD, RM>;                                                    \
-        static bool lds_limit_raised = false;      /* per instantiation; the call is idempotent, a race is harmless */    \
-        if (!lds_limit_raised) {                                                                                          \
+        static bool lds_limit_raised[32] = {};     /* per instantiation AND device (one engine process drives several */  \
+        int dev_ = 0;                              /* GPUs); the call is idempotent, a race is harmless */                 \
+        (void)hipGetDevice(&dev_);                                                                                        \
+        if (!lds_limit_raised[dev_ & 31]) {                                                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                       (int)lds);                                                                          \
-            lds_limit_raised = true;                                                                                      \
+            lds_limit_raised[dev_ & 31] = true;                                                                           \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
     } while (0)
