@@ -89,6 +89,7 @@ struct BatchStrides {
     int64_t x, w, y, bias;
     int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
     int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
+    int relu_sq;       // EPI_F16 only: y = relu(binary16(x.w + bias))^2 in the epilogue (unsplit launches need no reduce)
 };
 
 // Problems that share only M, K, ldx, ldw and the split count (a "grouped" launch: R/K/V and the four LoRA
@@ -476,7 +477,14 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
                 if (EPI == EPI_F16) {
                     f16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) o[e] = (f16)(bias ? v[e] + (float)bias[n + e] : v[e]);
+                    for (int e = 0; e < 4; e++) {
+                        float t = bias ? v[e] + (float)bias[n + e] : v[e];
+                        if (bs.relu_sq) {
+                            t = (float)(f16)t;               // relu(fp16(y))**2, rwkv7.py:678
+                            t = t > 0.f ? t * t : 0.f;
+                        }
+                        o[e] = (f16)t;
+                    }
                     *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldyp + n) = o;
                 } else {
                     *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * Np + n) = v;
@@ -741,7 +749,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
         return CHIRRUP_E_ALIGN;
     const int s = pick_splits(N, K, splits);
-    const bool partial = s > 1 || act != 0;
+    const bool partial = s > 1 || (act != 0 && !(g_mode && act == 1));     // unsplit relu^2 runs in the ring kernel's epilogue
     if (partial && !workspace) return CHIRRUP_E_NULL;
     const int MT = (M + 31) / 32;
     const int k_slice = K / s;
@@ -751,6 +759,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     int rc;
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
+    bs.relu_sq = (!partial && act == 1) ? 1 : 0;
     if (g_mode)
         rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y,
                                                        ldy, (const f16 *)bias, (float *)workspace, bs)
