@@ -128,6 +128,44 @@ def wkv7_event_timing(model, state, B, iters=6, fused=True):
     return ms[len(ms) // 2]
 
 
+def gemm_event_timing(model, B, iters=6):
+    """Average duration (ms) of the ring-GEMM launch that dominates the step by time, at the ffn.value shape
+    ([B, 4C] x [4C, C]^T, split 8, fp32 partials): HIP-graph replay of L back-to-back launches, one per layer's own
+    weight (L x 134 MB in rotation at 7.2B >> the 256 MiB Infinity Cache).  None when the model does not use the
+    hand-written path (mm8 FFN)."""
+    from chirrup_amd import ops
+
+    C, L = model.n_embd, model.n_layer
+    dev = model.device
+    if any(lw.f_V is None for lw in model._layers) or B > 256:
+        return None
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    x = torch.randn((B, 4 * C), generator=g, device=dev).half()
+    pbuf = torch.empty((8, B, C), dtype=torch.float32, device=dev)
+    ws = [lw.f_V_t if lw.f_V_t is not None else lw.f_V.t() for lw in model._layers]
+
+    def run():
+        for w in ws:
+            ops.skinny_linear_partial(x, w, 8, pbuf)
+
+    run()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    ms = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / L)
+    ms = sorted(ms[1:])
+    return ms[len(ms) // 2]
+
+
 def recorded_traffic(B, C, fused=False):
     """HBM bytes per WKV7 launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate runs, gfx950 correction applied) -- only when they were taken at this shape."""
@@ -299,6 +337,7 @@ def main():
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
     wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
+    gemm_ms = gemm_event_timing(model, B)
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -335,6 +374,14 @@ def main():
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if gemm_ms is not None:
+            # the kernel with the largest share of the step: algorithmic bytes = the weight once + x in + fp32 partials out
+            gb = 4 * C * C * 2 + B * 4 * C * 2 + 8 * B * C * 4
+            out["gemm_roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_ring_kernel at the ffn.value shape (split 8, fp32 partials)",
+                                    "bytes_per_launch": gb, "launch_us": round(gemm_ms * 1e3, 2),
+                                    "achieved": round(gb / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(gb / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches_per_step": 4 * L,
+                                    "note": "four launches of this kernel per layer (R/K/V+LoRA, att.output, ffn.key, ffn.value)"}
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, B, a.cpu_layers)
         print(json.dumps(out), flush=True)
