@@ -60,7 +60,8 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
 
 // Load row (x + delta) as binary16, return its layer-norm in `out` (binary16 values held as float).
 // If x_out != nullptr the summed row is stored there.
-__device__ __forceinline__ void ln_row(const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
+// x and x_out may alias (the in-place residual update of a decode step), so neither is __restrict__.
+__device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
                                        const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
                                        float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
                                        int dsplits = 0, int64_t dsplit_stride = 0) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void ln_row(const f16 *__restrict__ x, const f16 *__r
 // One workgroup per (b, t) row.
 template <int NMIX>
 __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
-    const int T, const int C, const f16 *__restrict__ x, const f16 *__restrict__ delta, f16 *__restrict__ x_out,
+    const int T, const int C, const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
     const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride) {
@@ -326,6 +327,9 @@ extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, c
     if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
     if (n_mix > 0 && (!prev_in || !prev_out || !mix)) return CHIRRUP_E_NULL;
     if (n_mix > 0 && T > 1 && prev_in == prev_out) return CHIRRUP_E_UNSUPPORTED;  // rows race on the carry
+    // T > 1: the workgroup of row t recomputes LN(x[t-1] + delta[t-1]) for the token shift while the workgroup of row
+    // t-1 stores x_out[t-1]; in place that is a cross-workgroup race (delta added twice when the store lands first)
+    if (n_mix > 0 && T > 1 && x_out == x && (delta || delta_partials)) return CHIRRUP_E_UNSUPPORTED;
     if (delta_partials && (delta || delta_splits <= 0)) return CHIRRUP_E_UNSUPPORTED;
     if (mis16(delta_partials)) return CHIRRUP_E_ALIGN;
     if (mis16(x) || mis16(delta) || mis16(x_out) || mis16(ln_w) || mis16(ln_b) || mis16(prev_in) || mis16(prev_out) ||

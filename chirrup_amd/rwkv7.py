@@ -405,6 +405,9 @@ class RWKV_x070:
         if not self.fuse_tmix_core:
             y, neg_kk, kka = new(B, T, C), new(B, T, C), new(B, T, C)
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
+        # T > 1: the LN kernel's row t re-reads x[t-1] (+ delta[t-1]) for the token shift, so the updated residual
+        # stream must not be written over x while other rows of the launch still read it: ping-pong two buffers
+        x_alt = torch.empty_like(x) if T > 1 else None
         delta, v_first = None, None
         dparts = None                     # split-K partials of the previous ffn.value GEMM (summed by the next LN kernel)
         # decode-batch regime of the hand-written MFMA GEMMs: time-mix projections for either FFN dtype (`hw`), the fp16
@@ -427,9 +430,12 @@ class RWKV_x070:
                     raise ops._lib.ChirrupAmdError("state[0][layer][j] view must be contiguous (slice the batch dim only)")
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
-            ops.add_ln_mix(B, T, C, x, delta, x if (delta is not None or dparts is not None) else None, lw.ln1_w, lw.ln1_b,
+            upd = delta is not None or dparts is not None
+            ops.add_ln_mix(B, T, C, x, delta, (x if T == 1 else x_alt) if upd else None, lw.ln1_w, lw.ln1_b,
                            1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts)
             if T > 1:
+                if upd:
+                    x, x_alt = x_alt, x
                 commit_carry(prev)
             # planes: 0 r, 1 k, 2 v, 3 w, 4 a, 5 g
             p0 = 1 if i == 0 else 0                                                           # layer 0 has no v gate
@@ -490,13 +496,14 @@ class RWKV_x070:
             prev = s0[i][1]
             if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
                 aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, 4, pbuf_o)   # split 4: half the partial traffic of 8 (7.77 -> 7.72 ms); reduce folded into the LN below
-                ops.add_ln_mix(B, T, C, x, None, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
-                               lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
+                ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
             else:
                 att = F.linear(o_in, lw.O)
-                ops.add_ln_mix(B, T, C, x, att, x, lw.ln2_w, lw.ln2_b, 1e-5, prev, prev if T == 1 else carry,
-                               lw.f_x_k.view(1, C), kin, slot_idx)
+                ops.add_ln_mix(B, T, C, x, att, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx)
             if T > 1:
+                x, x_alt = x_alt, x
                 commit_carry(prev)
             if self.ffn_dtype == torch.int8:        # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)
@@ -644,19 +651,30 @@ class SlotDecodeGraph:
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):
             t.copy_(s_)
-        self._tok_host = torch.zeros((B, 1), dtype=torch.long).pin_memory()
-        self._idx_host = torch.zeros((B,), dtype=torch.int32).pin_memory()
+        # two pinned staging pairs, used alternately: with run-ahead the host prepares step k+1 while the H2D copies
+        # of step k may still be queued; a pair is rewritten only after the event behind ITS last copies has passed
+        self._stage = [[torch.zeros((B, 1), dtype=torch.long).pin_memory(), torch.zeros((B,), dtype=torch.int32).pin_memory(), None]
+                       for _ in range(2)]
+        self._runs = 0
 
     def run(self, tokens: Sequence[int], slots: Sequence[int]) -> torch.Tensor:
         """tokens[i] goes to slot slots[i]; returns the static logits tensor, rows [0, len(slots)) valid."""
         n = len(slots)
         assert n <= self.B and len(tokens) == n
-        self._tok_host.zero_()
-        self._idx_host.fill_(self.parking)
-        self._tok_host[:n, 0] = torch.as_tensor(tokens, dtype=torch.long)
-        self._idx_host[:n] = torch.as_tensor(slots, dtype=torch.int32)
-        self.tokens.copy_(self._tok_host, non_blocking=True)
-        self.slot_idx.copy_(self._idx_host, non_blocking=True)
+        st = self._stage[self._runs & 1]
+        self._runs += 1
+        tok_host, idx_host, copied = st
+        if copied is not None:
+            copied.synchronize()
+        tok_host.zero_()
+        idx_host.fill_(self.parking)
+        tok_host[:n, 0] = torch.as_tensor(tokens, dtype=torch.long)
+        idx_host[:n] = torch.as_tensor(slots, dtype=torch.int32)
+        self.tokens.copy_(tok_host, non_blocking=True)
+        self.slot_idx.copy_(idx_host, non_blocking=True)
+        if st[2] is None:
+            st[2] = torch.cuda.Event()
+        st[2].record()
         self.graph.replay()
         return self.logits
 

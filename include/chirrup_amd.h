@@ -98,7 +98,8 @@ int mm8_one(int N, int M, const void *x, const void *w, int w_stride, const void
  * in the reference's eager execution, reductions accumulate in binary32.  All tensors binary16,
  * rows of C channels, C % 64 == 0, 16-byte aligned.
  *
- * rwkv7_add_ln_mix: x_new = x (+ delta, may be NULL) -> x_out (may be NULL or alias x);
+ * rwkv7_add_ln_mix: x_new = x (+ delta, may be NULL) -> x_out (may be NULL; may alias x when T == 1 -- with T > 1, a
+ *   delta and n_mix > 0 it must be a different buffer: row t re-reads x[t-1] + delta[t-1] for the token shift);
  *   cur = LayerNorm(x_new; ln_w, ln_b, eps); with n_mix in {1, 6}: token shift against the previous
  *   row (t > 0) or prev_in[b] (t == 0), out[m] = cur + (prev - cur) * mix[m], prev_out[b] = cur of
  *   the last row; with n_mix == 0: out = cur.   x,delta,x_out,out[m]: [B][T][C]; prev_*: [B][C];

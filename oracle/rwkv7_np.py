@@ -23,14 +23,39 @@ def _h(x):
     return np.asarray(x).astype(F16)
 
 
+# Accumulation order inside a matmul is a library choice in the reference (cuBLAS / hipBLAS).  ACC_SPLIT > 1 evaluates
+# every matmul as ACC_SPLIT binary32 partial sums over equal K ranges, added in order: a SECOND legitimate evaluation of
+# the same reference arithmetic.  Tests use the distance between the two as the noise floor a third evaluation (the
+# GPU's) has to stay within (tests/test_fullsize_gpu.py).
+ACC_SPLIT = 1
+
+
+def set_accumulation_split(n: int) -> int:
+    global ACC_SPLIT
+    old, ACC_SPLIT = ACC_SPLIT, max(1, int(n))
+    return old
+
+
+def _mm32(a32, b32):
+    """a32 [.., K] @ b32 [K, M] in binary32, as ACC_SPLIT ordered partial sums."""
+    K = a32.shape[-1]
+    if ACC_SPLIT <= 1 or K % ACC_SPLIT:
+        return a32 @ b32
+    step = K // ACC_SPLIT
+    acc = a32[..., :step] @ b32[:step]
+    for s in range(1, ACC_SPLIT):
+        acc = acc + a32[..., s * step:(s + 1) * step] @ b32[s * step:(s + 1) * step]
+    return acc
+
+
 def matmul_f16(x, w_t):
     """x [.., K] f16 @ w_t [K, M] f16 -> f16, binary32 accumulate."""
-    return (x.astype(F32) @ w_t.astype(F32)).astype(F16)
+    return _mm32(x.astype(F32), w_t.astype(F32)).astype(F16)
 
 
 def linear(x, w, bias=None):
     """F.linear: x @ w.T (+ bias, added before the single rounding)."""
-    acc = x.astype(F32) @ w.astype(F32).T
+    acc = _mm32(x.astype(F32), w.astype(F32).T)
     if bias is not None:
         acc = acc + bias.astype(F32)
     return acc.astype(F16)
@@ -128,17 +153,32 @@ def cmix(x, x_prev, x_k, K_, V_):
     return matmul_f16(k, V_)
 
 
-def cmix_mm8(x, x_prev, x_k, K8, V8):
+def mm8_seq_blas(x, q, mx, rx, my, ry):
+    """The as-coded mm8 product (scripts/test_mm8/rwkv_pip_operators.cu:76-79: dq = (w + 0.5) * rx[k] * ry[j] + mx[k] +
+    my[j], left to right in binary32; y = binary16(sum_j x[i,j] * dq[j,k])) with the sum over j left to BLAS instead of
+    oracle_mm8_seq's sequential j loop -- for the full-size shapes (200 x 4096 x 16384), where that loop takes
+    minutes.  Same per-element dequantisation; only the binary32 summation order differs (checked against
+    oracle_mm8_seq in tests/test_oracle_cpu.py)."""
+    dq = q.astype(F32) + F32(0.5)
+    dq *= rx.astype(F32).reshape(1, -1)
+    dq *= ry.astype(F32).reshape(-1, 1)
+    dq += mx.astype(F32).reshape(1, -1)
+    dq += my.astype(F32).reshape(-1, 1)
+    return _mm32(x.astype(F32), dq).astype(F16)
+
+
+def cmix_mm8(x, x_prev, x_k, K8, V8, blas=False):
     """Channel-mix with the two matmuls through mm8 (w8a16): same token shift and relu^2 as cmix,
     the products evaluated by the as-coded mm8 kernel restatement (oracle.c: oracle_mm8_seq, following
-    scripts/test_mm8/rwkv_pip_operators.cu:59-83).  K8 / V8 = (q [N,M], mx, rx, my, ry)."""
+    scripts/test_mm8/rwkv_pip_operators.cu:59-83; blas=True: mm8_seq_blas).  K8 / V8 = (q [N,M], mx, rx, my, ry)."""
     B, T, C = x.shape
+    mm = mm8_seq_blas if blas else native.mm8_seq
     xx = _shift(x, x_prev[1])
     x_prev[1] = x[:, -1, :]
     k = (x + xx * x_k).reshape(B * T, C)
-    k = np.maximum(native.mm8_seq(k, *K8), F16(0))
+    k = np.maximum(mm(k, *K8), F16(0))
     k = k * k
-    return native.mm8_seq(k, *V8).reshape(B, T, C)
+    return mm(k, *V8).reshape(B, T, C)
 
 
 def quantize_ffn(z, n_layer):
@@ -150,7 +190,7 @@ def quantize_ffn(z, n_layer):
     return out
 
 
-def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None):
+def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None, mm8_blas=False):
     """forward_seq_batch_seperate = _pre/_layers/_post, Albatross/rwkv7.py:503-563.
     tokens [B][T] ints (equal lengths); state = [s0 [L,2,B,C], s1 [L,B,H,64,64], s2 [B] int32],
     all numpy, updated IN PLACE.  Returns logits f16 [B,V] (or [B,T,V])."""
@@ -168,7 +208,7 @@ def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None):
         x = x + xx
         xx = layer_norm(x, z[bbb + "ln2.weight"], z[bbb + "ln2.bias"])
         if mm8 is not None:
-            xx = cmix_mm8(xx, s0[i], z[ffn + "x_k"], *mm8[i])
+            xx = cmix_mm8(xx, s0[i], z[ffn + "x_k"], *mm8[i], blas=mm8_blas)
         else:
             xx = cmix(xx, s0[i], z[ffn + "x_k"], z[ffn + "key.weight"], z[ffn + "value.weight"])
         x = x + xx

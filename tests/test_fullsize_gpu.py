@@ -1,0 +1,184 @@
+"""Whole-step parity at the PRODUCTION shapes of BASELINE.json's configs 3 and 5 (7.2B: C=4096, V=65536, bsz 200;
+13.3B: the same width, bsz 64) -- the 32-/61-layer graphs bench.py times are these layers repeated -- and the
+prefill (T > 1) call sites of the LN / token-shift kernel at production row counts.
+
+Oracle = oracle/rwkv7_np.py on the same synthetic weights (the reference arithmetic: Albatross/rwkv7.py:503-563,
+:618-649, :673-679; mm8: scripts/test_mm8/rwkv_pip_operators.cu:59-83).  Bar, as in tests/test_model_gpu.py: the
+GPU result has to be as close to the oracle as a SECOND CPU evaluation of the same arithmetic in another summation
+order is (rwkv7_np.ACC_SPLIT = 4) -- within max(1e-3, 2x that floor + 5e-4) -- and within 5e-3 of the tensor's scale
+in any case; greedy ids equal on every row whose top-2 logit margin is >= 0.03; elapsed_t exact.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import bits
+
+pytestmark = pytest.mark.gpu
+F16, F32 = np.float16, np.float32
+C, V = 4096, 65536
+
+
+def rel_linf(got, want):
+    w = want.astype(F32)
+    return float(np.abs(got.astype(F32) - w).max() / max(1.0, float(np.abs(w).max())))
+
+
+def _args():
+    return types.SimpleNamespace(vocab_size=V, head_size=64, MODEL_NAME="unused")
+
+
+@pytest.fixture(scope="module")
+def big():
+    """A 3-layer C=4096 / V=65536 synthetic checkpoint (generated on the GPU: 0.8 G normal deviates) and its
+    numpy-oracle form.  Layers 0-1 are the "7.2B shape" model, all three the "13.3B shape" one."""
+    from chirrup_amd.synth import make_state_dict
+    from oracle import rwkv7_np as M
+
+    zd = make_state_dict(3, C, V, seed=42, device="cuda:0")
+    z_np = M.prepare_weights({k: v.cpu().numpy() for k, v in zd.items()})
+    return zd, z_np
+
+
+def _random_state(L, B, seed):
+    rng = np.random.default_rng(seed)
+    return [(rng.standard_normal((L, 2, B, C)) * 0.5).astype(F16),
+            (rng.standard_normal((L, B, C // 64, 64, 64)) * 0.1).astype(F16),            # N(0, 0.1)
+            (np.arange(B) * 7 + 3).astype(np.int32)]
+
+
+def _one_graph_step_vs_oracle(zd, z_np, L, B, int8, seed):
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from oracle import rwkv7_np as M
+
+    sub = {k: v for k, v in zd.items() if not (k.startswith("blocks.") and int(k.split(".")[1]) >= L)}
+    model = RWKV_x070(_args(), state_dict=sub, device="cuda:0", ffn_dtype=torch.int8 if int8 else torch.float16)
+    assert model.n_layer == L and model._layers[0].rkv_t is not None          # the shipped configuration: tiled ring GEMMs
+    mm8 = M.quantize_ffn(z_np, L) if int8 else None
+    st0 = _random_state(L, B, seed)
+    rng = np.random.default_rng(seed + 1)
+    toks = rng.integers(1, V, size=(B, 1)).tolist()
+
+    def run_np(split):
+        old = M.set_accumulation_split(split)
+        try:
+            st = [t.copy() for t in st0]
+            return M.forward_seq_batch(z_np, toks, st, L, mm8=mm8, mm8_blas=True), st
+        finally:
+            M.set_accumulation_split(old)
+
+    lg_np, st_np = run_np(1)
+    lg_alt, st_alt = run_np(4)
+    floor = {"logits": rel_linf(lg_alt, lg_np), "wkv": rel_linf(st_alt[1], st_np[1]), "shift": rel_linf(st_alt[0], st_np[0])}
+
+    st = [torch.from_numpy(t.copy()).cuda() for t in st0]
+    graph = model.capture_decode_graph(st)                                     # ONE captured decode step, as bench.py replays it
+    assert all(np.array_equal(bits(a.cpu().numpy()), bits(b)) for a, b in zip(st[:2], st0[:2]))
+    lg = graph.step(toks).cpu().numpy()
+    err = {"logits": rel_linf(lg, lg_np), "wkv": rel_linf(st[1].cpu().numpy(), st_np[1]),
+           "shift": rel_linf(st[0].cpu().numpy(), st_np[0])}
+    print(f"L={L} B={B} int8={int8}: err {err} floor {floor}")
+    assert st[2].cpu().numpy().tolist() == st_np[2].tolist()
+    extra = 1e-3 if int8 else 5e-4          # mm8: the split form rounds xs = x*ry to binary16 (benchmark.py:169), the as-coded oracle does not
+    # north_star's "state within 1e-3" where two CPU evaluations of the reference arithmetic themselves agree that well;
+    # otherwise their distance sets the bar (tests/test_golden_cpu.py::test_c768_... measures 1.1e-3 between numpy and
+    # the reference's own torch-CPU run at C = 768)
+    for name in err:
+        assert err[name] <= min(5e-3, max(1e-3, 2 * floor[name] + extra)), (name, err, floor)
+    top2 = np.sort(lg_np.astype(F32), axis=-1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) >= 0.03
+    assert clear.sum() >= B // 2
+    assert np.array_equal(lg.astype(F32).argmax(-1)[clear], lg_np.astype(F32).argmax(-1)[clear])
+    del graph, model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("int8", [False, True], ids=["fp16", "mm8"])
+def test_7b_shape_graph_step_vs_oracle(big, int8, oracle):
+    """BASELINE config 3: two layers of the 7.2B shape at bsz 200, fp16 and ffn_dtype=int8."""
+    _one_graph_step_vs_oracle(*big, L=2, B=200, int8=int8, seed=11)
+
+
+def test_13b_shape_graph_step_vs_oracle(big, oracle):
+    """BASELINE config 5's model step: three layers of the 13.3B shape at bsz 64 (the 64-row GEMM tiles)."""
+    _one_graph_step_vs_oracle(*big, L=3, B=64, int8=False, seed=12)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _ln_mix_oracle(xn, w, b, prev, mix):
+    from oracle import rwkv7_np as M
+
+    cur = M.layer_norm(xn, w, b)
+    dx = np.concatenate([prev[:, None], cur[:, :-1]], 1) - cur
+    return np.stack([cur + dx * mix[m] for m in range(mix.shape[0])]), cur
+
+
+@pytest.mark.parametrize("B,T,n_mix,parts", [(25, 100, 6, False), (25, 100, 1, False), (2, 100, 6, True), (2, 100, 1, True)])
+def test_add_ln_mix_prefill_call_sites_at_production_shape(B, T, n_mix, parts):
+    """The T > 1 forms _forward_embedded_fused issues (a delta, or the split-K partials of the previous GEMM at
+    <= 256 rows) with the residual stream written to a SECOND buffer: row t's workgroup re-reads x[t-1] + delta[t-1]
+    while row t-1's workgroup stores x_new[t-1], so an in-place update is a cross-workgroup race (round-1 advisor
+    finding) and is refused by the C entry."""
+    from chirrup_amd import lib, ops
+
+    rng = np.random.default_rng(B + T + n_mix)
+    rows = B * T
+    x = rng.standard_normal((B, T, C)).astype(F16)
+    w = (1 + 0.1 * rng.standard_normal(C)).astype(F16)
+    b = (0.1 * rng.standard_normal(C)).astype(F16)
+    prev = rng.standard_normal((B, C)).astype(F16)
+    mix = rng.uniform(0, 1, (n_mix, C)).astype(F16)
+    if parts:
+        dp = (rng.standard_normal((8, rows, C)) * 0.2).astype(F32)
+        delta = dp.sum(0, dtype=F32).astype(F16).reshape(B, T, C)          # summed in split order in the kernel too
+    else:
+        dp, delta = None, (rng.standard_normal((B, T, C)) * 0.5).astype(F16)
+    xn = x + delta
+    want, cur = _ln_mix_oracle(xn, w, b, prev, mix)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tx, tprev = cu(x), cu(prev)
+    x_new, carry = torch.empty_like(tx), torch.empty_like(tprev)
+    out = torch.empty((n_mix, B, T, C), dtype=torch.float16, device="cuda")
+    kw = dict(delta_partials=cu(dp)) if parts else {}
+    with pytest.raises(lib.ChirrupAmdError):                                   # in place with T > 1: refused
+        ops.add_ln_mix(B, T, C, tx, None if parts else cu(delta), tx, cu(w), cu(b), 1e-5, tprev, carry, cu(mix), out, **kw)
+    for _ in range(3):                                                         # repeated: the answer never depends on block timing
+        ops.add_ln_mix(B, T, C, tx, None if parts else cu(delta), x_new, cu(w), cu(b), 1e-5, tprev, carry, cu(mix), out, **kw)
+        got_x = x_new.cpu().numpy()
+        if parts:
+            assert np.abs(got_x.astype(F32) - xn.astype(F32)).max() <= 8e-3    # fp32 sum order of 8 partials: <= 1 ulp at |x| < 8
+        else:
+            assert np.array_equal(bits(got_x), bits(xn))
+        assert np.array_equal(bits(tx.cpu().numpy()), bits(x))                 # the input stream is left alone
+        d = np.abs(out.cpu().numpy().astype(F32) - want.astype(F32))
+        assert d.max() <= (8e-3 if not parts else 2e-2), d.max()               # one-ulp flips at |LN| ~ 4-8 through a lerp
+        assert (d > 4e-3).mean() < 1e-3
+        assert np.abs(carry.cpu().numpy().astype(F32) - cur[:, -1].astype(F32)).max() <= 8e-3
+
+
+def test_prefill_chunk_equals_tokens_fed_one_at_a_time_at_production_width(big):
+    """forward_slots with a 25 x 40 chunk (1000 rows: the library-GEMM prefill path, residual stream ping-ponged
+    between two buffers) against the same tokens fed one decode step at a time (200-row regime: ring GEMMs, residual
+    updated in place) on a 2-layer C=4096 model: states agree to the rounding noise of 40 tokens.  A delta added twice
+    to a row (the race the in-place T > 1 update allowed) would show as an O(1) error."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    zd, _ = big
+    sub = {k: v for k, v in zd.items() if not (k.startswith("blocks.") and int(k.split(".")[1]) >= 2)}
+    model = RWKV_x070(_args(), state_dict=sub, device="cuda:0")
+    B, T, n_slots = 25, 40, 32
+    rng = np.random.default_rng(5)
+    toks = rng.integers(1, V, size=(B, T))
+    slots = torch.tensor(rng.permutation(n_slots)[:B].astype(np.int32)).cuda()
+    pool_a, pool_b = model.generate_zero_state(n_slots), model.generate_zero_state(n_slots)
+    lg_a = model.forward_slots(toks.tolist(), pool_a, slots)
+    for t in range(T):
+        lg_b = model.forward_slots(toks[:, t:t + 1].tolist(), pool_b, slots)
+    assert pool_a[2].tolist() == pool_b[2].tolist()
+    e_wkv = rel_linf(pool_a[1].cpu().numpy(), pool_b[1].cpu().numpy())
+    e_shift = rel_linf(pool_a[0].cpu().numpy(), pool_b[0].cpu().numpy())
+    e_lg = rel_linf(lg_a.cpu().numpy(), lg_b.cpu().numpy())
+    print(f"chunk vs token-by-token: wkv {e_wkv:.2e} shift {e_shift:.2e} logits {e_lg:.2e}")
+    assert e_wkv <= 1e-2 and e_shift <= 1e-2 and e_lg <= 1e-2

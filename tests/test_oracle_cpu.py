@@ -147,3 +147,30 @@ def test_spmv_oracle(oracle):
     assert np.allclose(out.astype(np.float64), want, rtol=2e-3, atol=2e-3)
     out2 = oracle.spmv(vec, mat, out=out.copy())  # accumulates
     assert np.allclose(out2.astype(np.float64), 2 * want, rtol=4e-3, atol=4e-3)
+
+
+def test_blas_mm8_and_split_accumulation_agree_with_the_as_coded_oracle(oracle):
+    """The two helpers the full-size GPU tests lean on (oracle/rwkv7_np.py): mm8_seq_blas = the as-coded mm8 product
+    with the j sum left to BLAS, and ACC_SPLIT = the same matmuls as ordered partial sums.  Both are the reference
+    arithmetic in another summation order: results equal oracle_mm8_seq / the plain evaluation to binary16 rounding
+    (at most one ulp on a few elements)."""
+    from oracle import rwkv7_np as M
+
+    rng = np.random.default_rng(9)
+    B, N, Mo = 7, 256, 192
+    w16 = (rng.standard_normal((N, Mo)) / 16).astype(F16)
+    q, mx, rx, my, ry = M.quantize_weight(w16)
+    x = rng.standard_normal((B, N)).astype(F16)
+    want = oracle.mm8_seq(x, q, mx, rx, my, ry)
+    got = M.mm8_seq_blas(x, q, mx, rx, my, ry)
+    d = np.abs(got.astype(np.float32) - want.astype(np.float32))
+    assert d.max() <= 2e-3 * max(1.0, float(np.abs(want.astype(np.float32)).max())) and (got != want).mean() < 0.02
+    old = M.set_accumulation_split(4)
+    try:
+        got4 = M.mm8_seq_blas(x, q, mx, rx, my, ry)
+        lin4 = M.linear(x, w16.T.copy())
+    finally:
+        M.set_accumulation_split(old)
+    lin1 = M.linear(x, w16.T.copy())
+    assert (got4 != want).mean() < 0.02 and (lin4 != lin1).mean() < 0.02
+    assert np.abs(lin4.astype(np.float32) - lin1.astype(np.float32)).max() <= 2e-3

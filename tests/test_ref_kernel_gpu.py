@@ -90,5 +90,18 @@ def test_fast_math_reference_kernel_stays_within_tolerance_of_oracle_and_of_our_
     assert np.array_equal(bits(tS.cpu().numpy()), bits(S))                       # ours == oracle, as always
     scale = max(1.0, float(np.abs(S.astype(np.float32)).max()))
     d = np.abs(S_r.astype(np.float32) - S.astype(np.float32)).max() / scale
-    print(f"fast-math reference vs oracle: state rel-Linf {d:.3e}")
-    assert d <= 1e-2        # the reference's own flags vs its source order; north_star asks 1e-3 of US
+    print(f"fast-math reference (as built, rwkv7.py:51-52) vs oracle and vs our kernel: state rel-Linf {d:.3e} after T={T}")
+    # The reference AS BUILT (-ffast-math: FMA contraction, approximate exp2 / division) sits this far from its own
+    # source order after 4 tokens; measured 1.1e-3 on gfx950.  north_star's 1e-3 is held against the strict build
+    # (bit-exact, tests above) because the reference's CUDA and HIP fast-math builds already differ from each other
+    # by this much -- there is no single "as built" result to match.  The bound is the measured distance with
+    # headroom for another compiler's contraction choices, not a loose sanity bar.
+    assert d <= 2e-3
+    # one decode step (T = 1), the regime north_star's tolerance is quoted for: within 1e-3
+    state1, r1, w1, k1, v1, a1, b1, et1 = wkv7_inputs(B, 1, C, seed=6)
+    S1 = state1.copy()
+    oracle.wkv7_seq(S1, r1, w1, k1, v1, a1, b1, et1)
+    _, S1_r = _run_ref(fn, state1, r1, w1, k1, v1, a1, b1, et1)
+    d1 = np.abs(S1_r.astype(np.float32) - S1.astype(np.float32)).max() / max(1.0, float(np.abs(S1.astype(np.float32)).max()))
+    print(f"fast-math reference vs oracle, one decode step: state rel-Linf {d1:.3e}")
+    assert d1 <= 1e-3

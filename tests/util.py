@@ -30,3 +30,35 @@ def wkv7_inputs(B, T, C, seed=0, n_slots=None, state_scale=0.5, elapsed="arange"
 
 def bits(x):
     return np.ascontiguousarray(x).view(np.uint16)
+
+
+def c768_fixture():
+    """(fixture, checkpoint dict) of tests/golden/model_L3_C768.npz: outputs of the REFERENCE's
+    forward_seq_batch_seperate (tests/golden/make_golden.py::gen_model_c768) on seed-generated weights that are
+    rebuilt here and proven identical through the stored sha256."""
+    import hashlib
+    import os
+
+    from chirrup_amd.synth import make_state_dict
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_L3_C768.npz"))
+    L, C, V, B, seed = (int(v) for v in d["config"])
+    zd = make_state_dict(L, C, V, seed=seed, varied_norms=True)
+    h = hashlib.sha256()
+    for k in sorted(zd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(zd[k].numpy()).tobytes())
+    assert h.hexdigest() == d["weights_sha256"].tobytes().decode(), "synthetic weights differ from the fixture's (torch RNG changed?)"
+    return d, zd
+
+
+def c768_inputs(d, tag):
+    """The seeded inputs of case `tag` (state tensors are regenerated, not stored)."""
+    L, C, V, B, _ = (int(v) for v in d["config"])
+    rng = np.random.default_rng(int(d[f"{tag}:seed"][0]))
+    s0 = (rng.standard_normal((L, 2, B, C)) * 0.5).astype(np.float16)
+    s1 = (rng.standard_normal((L, B, C // 64, 64, 64)) * 0.1).astype(np.float16)
+    s2 = (np.arange(B) * 7 + 3).astype(np.int32)
+    toks = rng.integers(1, V, size=d[f"{tag}:tokens"].shape).tolist()
+    assert toks == d[f"{tag}:tokens"].tolist()
+    return toks, [s0, s1, s2]
