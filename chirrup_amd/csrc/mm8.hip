@@ -4,12 +4,17 @@
 // scripts/test_mm8/rwkv_pip_operators.cu:59-97, :150-189, :205-558; formulas
 // scripts/test_mm8/benchmark.py:114-118 (direct) and :167-179 (algebraic split).
 //
-// Two code paths:
-//   mm8_seq  (B rows)  "direct" kernel: the as-coded expression, binary32 accumulate over j in
-//            order, one rounding per operation -> bit-identical to oracle_mm8_seq.  A workgroup
-//            owns 32 batch rows x 256 output columns; the dequantised weight is formed once
-//            per (j,k) and reused for the 32 rows, x is broadcast from LDS.
-//            TODO(round 2): MFMA path (u8 -> f16 in registers, v_mfma_f32_32x32x16_f16).
+// Code paths:
+//   mm8_seq / mm8_seq_opt (B rows; the reference's op names, rwkv_pip_wrapper.cpp:206-211, weights w [N][M] row-major):
+//            the MFMA path.  The uint8 matrix is re-laid once per call into the K-contiguous 8-KiB tile images of the
+//            ring GEMM (mm8_pack: a transposing copy through LDS, N*M bytes of workspace) and multiplied by mm8t_seq
+//            (csrc/skinny_gemm.hip: u8 -> f16 in registers, v_mfma_f32_32x32x16_f16, the reference's algebraically
+//            split form).  Callers with static weights pack once (mm8_pack) and call mm8t_seq(w_tiled = 1) themselves
+//            -- chirrup_amd.ops.mm8_seq caches the packed matrix per weight tensor.  Shapes the tile images cannot
+//            hold (N % 64, M % 128, 16-byte alignment) fall back to mm8_seq_direct.
+//   mm8_seq_direct      the as-coded expression, binary32 accumulate over j in order, one rounding per operation
+//            -> bit-identical to oracle_mm8_seq.  A workgroup owns 32 batch rows x 256 output columns; the
+//            dequantised weight is formed once per (j,k) and reused for the 32 rows, x is broadcast from LDS.
 //   mm8_one  (GEMV)    split over j like the reference (24 slices in the reference, here
 //            enough slices to fill the chip), binary32 atomicAdd into the caller-zeroed y.
 #include <hip/hip_runtime.h>
@@ -122,17 +127,94 @@ __global__ __launch_bounds__(kOneThreads) void mm8_one_kernel(
         if (k0 + c < M) atomicAdd(&y[k0 + c], acc[c]);
 }
 
+// w [N][M] uint8 row-major  ->  the ring GEMM's tile images of wT [M][N]: tile (ng = m / 128, kb = j / 64) is 512 chunks
+// of 16 B; chunk c holds, for output column m = 128 ng + (c >> 2), the 16 reduction indices j = 64 kb + 16 lc + (0..15)
+// with lc = (c & 3) ^ (((c >> 2) >> 2) & 3)  (the XOR swizzle of skinny_gemm.hip's uint8 W image).
+// One workgroup per tile: 64 rows x 128 B in (coalesced 16-B loads), transposed through LDS, 8 KiB out (coalesced).
+__global__ __launch_bounds__(256) void mm8_pack_kernel(const int N, const int M, const uint8_t *__restrict__ w,
+                                                       const int w_stride, uint8_t *__restrict__ out) {
+    __shared__ uint32_t tile[64][33];                     // [j][m / 4], rows padded by one dword
+    const int ng = blockIdx.x, kb = blockIdx.y, tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int j = p * 32 + (tid >> 3), c16 = tid & 7;
+        const uint4 v = *reinterpret_cast<const uint4 *>(w + (int64_t)(kb * 64 + j) * w_stride + ng * 128 + c16 * 16);
+        tile[j][c16 * 4 + 0] = v.x, tile[j][c16 * 4 + 1] = v.y, tile[j][c16 * 4 + 2] = v.z, tile[j][c16 * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    uint8_t *dst = out + ((int64_t)ng * (N / 64) + kb) * 8192;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = p * 256 + tid;
+        const int nr = c >> 2, lc = (c & 3) ^ ((nr >> 2) & 3);
+        const int sh = 8 * (nr & 3);
+        uint32_t q[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc |= ((tile[lc * 16 + d * 4 + b][nr >> 2] >> sh) & 0xffu) << (8 * b);
+            q[d] = acc;
+        }
+        *reinterpret_cast<uint4 *>(dst + c * 16) = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+inline bool mfma_eligible(int N, int M, const void *x, int x_stride, const void *w, int w_stride, int y_stride) {
+    return N % 64 == 0 && M % 128 == 0 && (w_stride & 15) == 0 && (x_stride & 7) == 0 && (y_stride & 3) == 0 &&
+           (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
+inline int64_t round256(int64_t b) { return (b + 255) / 256 * 256; }
+
 }  // namespace
 
-extern "C" int64_t mm8_seq_workspace_bytes(int B, int N, int M) {
-    (void)B; (void)N; (void)M;
-    return 0;  // the direct kernel needs none; the MFMA path will stage xs = x*ry here
+extern "C" int64_t mm8_packed_bytes(int N, int M) {
+    return (N > 0 && M > 0 && N % 64 == 0 && M % 128 == 0) ? (int64_t)N * M : 0;
 }
+
+extern "C" int mm8_pack(int N, int M, const void *w, int w_stride, void *packed, void *stream) {
+    if (N <= 0 || M <= 0 || (N % 64) || (M % 128) || w_stride < M || (w_stride & 15)) return CHIRRUP_E_SHAPE;
+    if (!w || !packed) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15)) return CHIRRUP_E_ALIGN;
+    if (N / 64 > 65535) return CHIRRUP_E_SHAPE;
+    hipLaunchKernelGGL(mm8_pack_kernel, dim3(M / 128, N / 64), dim3(256), 0, static_cast<hipStream_t>(stream), N, M,
+                       static_cast<const uint8_t *>(w), w_stride, static_cast<uint8_t *>(packed));
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t mm8_seq_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0 || (N % 64) || (M % 128)) return 0;      // the direct kernel needs none
+    return round256((int64_t)N * M) + mm8t_workspace_bytes(B, N, M, 0) + 256;
+}
+
+extern "C" int mm8_seq_direct(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+                              const void *mx, const void *rx, const void *my, const void *ry, void *y,
+                              int y_stride, void *stream);
 
 extern "C" int mm8_seq(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
                        const void *mx, const void *rx, const void *my, const void *ry, void *y,
                        int y_stride, void *workspace, void *stream) {
-    (void)workspace;
+    if (B <= 0 || N <= 0 || M <= 0 || x_stride < N || w_stride < M || y_stride < M) return CHIRRUP_E_SHAPE;
+    if (!x || !w || !mx || !rx || !my || !ry || !y) return CHIRRUP_E_NULL;
+    if (!mfma_eligible(N, M, x, x_stride, w, w_stride, y_stride))
+        return mm8_seq_direct(B, N, M, x, x_stride, w, w_stride, mx, rx, my, ry, y, y_stride, stream);
+    if (!workspace) return CHIRRUP_E_NULL;
+    unsigned char *ws = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(workspace) + 255) / 256 * 256);
+    int rc = mm8_pack(N, M, w, w_stride, ws, stream);
+    if (rc) return rc;
+    return mm8t_seq(B, N, M, x, x_stride, ws, N, 1, mx, rx, my, ry, y, y_stride, 0, 0, ws + round256((int64_t)N * M), stream);
+}
+
+extern "C" int mm8_seq_opt(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+                           const void *mx, const void *rx, const void *my, const void *ry, void *y,
+                           int y_stride, void *workspace, void *stream) {
+    return mm8_seq(B, N, M, x, x_stride, w, w_stride, mx, rx, my, ry, y, y_stride, workspace, stream);
+}
+
+extern "C" int mm8_seq_direct(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+                              const void *mx, const void *rx, const void *my, const void *ry, void *y,
+                              int y_stride, void *stream) {
     if (B <= 0 || N <= 0 || M <= 0 || x_stride < N || w_stride < M || y_stride < M) return CHIRRUP_E_SHAPE;
     if (!x || !w || !mx || !rx || !my || !ry || !y) return CHIRRUP_E_NULL;
     const dim3 grid((M + kKT - 1) / kKT, (B + kBT - 1) / kBT);

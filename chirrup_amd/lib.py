@@ -31,6 +31,10 @@ SIGNATURES = {
     "spmv_fp16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mm8_seq_workspace_bytes": (_i64, [_i, _i, _i]),
     "mm8_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mm8_seq_opt": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mm8_seq_direct": (_i, [_i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mm8_packed_bytes": (_i64, [_i, _i]),
+    "mm8_pack": (_i, [_i, _i, _vp, _i, _vp, _vp]),
     "mm8_one": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f32p, _vp]),
     "rwkv7_add_ln_mix": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "rwkv7_tmix_mid": (_i, [_i64, _i] + [_vp] * 9 + [_vp]),

@@ -109,9 +109,7 @@ def rwkv_mm_sparsity(k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
-    """rwkv_pip::mm8_seq (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84): y[B,M] = x[B,N] @ dequant(w[N,M])."""
-    L = _lib.load()
+def _mm8_check(B, N, M, x, w, mx, rx, my, ry, y):
     for name, t in (("x", x), ("mx", mx), ("rx", rx), ("my", my), ("ry", ry), ("y", y)):
         if not t.is_cuda or t.dtype != torch.float16:
             raise _lib.ChirrupAmdError(f"{name}: expected a GPU fp16 tensor")
@@ -123,7 +121,73 @@ def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
         raise _lib.ChirrupAmdError("x, w, y need unit inner stride")
     if mx.numel() != M or rx.numel() != M or my.numel() != N or ry.numel() != N:
         raise _lib.ChirrupAmdError("mx,rx need M elements and my,ry need N elements")
-    mx, rx, my, ry = (t.contiguous() for t in (mx, rx, my, ry))
+    return tuple(t.contiguous() for t in (mx, rx, my, ry))
+
+
+# Packed (K-contiguous tile-image) copies of mm8 weight matrices, one per weight TENSOR: the reference's op takes the
+# uint8 matrix as [N, M] on every call, the matrix cores want it K-contiguous, and weights are static -- so the re-lay
+# (mm8_pack) runs once per tensor.  Keyed by (address, in-place version counter, shape); an entry keeps its source
+# tensor alive, so the address cannot be handed to another tensor while the entry exists.  Bounded by bytes.
+_MM8_PACK_CACHE: "OrderedDict" = None
+MM8_PACK_CACHE_BYTES = 32 << 30
+
+
+def _mm8_packed(w: torch.Tensor, N: int, M: int) -> Optional[torch.Tensor]:
+    """The packed form of w [N, M] (None when the shape cannot use the MFMA path)."""
+    global _MM8_PACK_CACHE
+    L = _lib.load()
+    if L.mm8_packed_bytes(N, M) == 0 or (w.stride(0) & 15) or (w.data_ptr() & 15):
+        return None
+    if _MM8_PACK_CACHE is None:
+        from collections import OrderedDict
+        _MM8_PACK_CACHE = OrderedDict()
+    key = (w.device.index, w.data_ptr(), w._version, N, M, w.stride(0))
+    hit = _MM8_PACK_CACHE.get(key)
+    if hit is not None:
+        _MM8_PACK_CACHE.move_to_end(key)
+        return hit[0]
+    packed = torch.empty((N * M,), dtype=torch.uint8, device=w.device)
+    _lib.check(L.mm8_pack(N, M, w.data_ptr(), w.stride(0), packed.data_ptr(), _stream()), "mm8_pack")
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()        # later calls may come from any stream
+        _MM8_PACK_CACHE[key] = (packed, w)
+        total = sum(e[0].numel() for e in _MM8_PACK_CACHE.values())
+        while total > MM8_PACK_CACHE_BYTES and len(_MM8_PACK_CACHE) > 1:
+            _, (old, _) = _MM8_PACK_CACHE.popitem(last=False)
+            total -= old.numel()
+    return packed
+
+
+def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """rwkv_pip::mm8_seq / mm8_seq_opt (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84, :206-211):
+    y[B,M] = x[B,N] @ dequant(w[N,M]), on the matrix cores (include/chirrup_amd.h: mm8_seq).  The weight is packed
+    once per tensor (see _mm8_packed); shapes the packed layout cannot hold run the as-coded kernel."""
+    L = _lib.load()
+    mx, rx, my, ry = _mm8_check(B, N, M, x, w, mx, rx, my, ry, y)
+    packed = _mm8_packed(w, N, M) if (x.stride(0) % 8 == 0 and y.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+    if packed is None:
+        rc = L.mm8_seq_direct(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(),
+                              my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), _stream())
+        return _lib.check(rc, "mm8_seq_direct")
+    ws = _workspace(L.mm8t_workspace_bytes(B, N, M, 0) + 256, x.device)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    rc = L.mm8t_seq(B, N, M, x.data_ptr(), x.stride(0), packed.data_ptr(), N, 1, mx.data_ptr(), rx.data_ptr(), my.data_ptr(),
+                    ry.data_ptr(), y.data_ptr(), y.stride(0), 0, 0, base, _stream())
+    _lib.check(rc, "mm8t_seq")
+
+
+def mm8_seq_direct(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """The as-coded kernel (rwkv_pip_operators.cu:59-83), bit-identical to the oracle; any shape, not MFMA."""
+    mx, rx, my, ry = _mm8_check(B, N, M, x, w, mx, rx, my, ry, y)
+    rc = _lib.load().mm8_seq_direct(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(),
+                                    rx.data_ptr(), my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), _stream())
+    _lib.check(rc, "mm8_seq_direct")
+
+
+def mm8_seq_stateless(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """The C ABI's own mm8_seq: packs w into the workspace on EVERY call (no cache), then the MFMA kernel."""
+    L = _lib.load()
+    mx, rx, my, ry = _mm8_check(B, N, M, x, w, mx, rx, my, ry, y)
     ws = _workspace(L.mm8_seq_workspace_bytes(B, N, M), x.device)
     rc = L.mm8_seq(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(),
                    my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), ws.data_ptr(), _stream())
@@ -503,6 +567,7 @@ def register_torch_ops() -> None:
         },
         "rwkv_pip": {
             "mm8_seq": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
+            "mm8_seq_opt": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
             "mm8_one": (f"(int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_one),
         },
     }

@@ -73,18 +73,34 @@ int spmv_fp16(int D, int C, const void *vec, const void *mat, void *out, void *w
 
 /*
  * mm8 (w8a16): y[i][k] = sum_j x[i][j] * ((w[j][k] + 0.5) * rx[k] * ry[j] + mx[k] + my[j]).
- * Replaces: rwkv_pip::mm8_seq  scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84 (kernels
- *           scripts/test_mm8/rwkv_pip_operators.cu:59-97 and the _opt / wmma forms :205-558).
+ * Replaces: rwkv_pip::mm8_seq and rwkv_pip::mm8_seq_opt  scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84, :206-211
+ *           (kernels scripts/test_mm8/rwkv_pip_operators.cu:59-97 and the _opt / wmma forms :205-558).
  * x [B][N] binary16 (row stride x_stride elements), w [N][M] uint8 (row stride w_stride),
  * mx,rx [M], my,ry [N] binary16, y [B][M] binary16 (row stride y_stride).
- * binary32 accumulate; evaluated in the algebraically split form of
- * scripts/test_mm8/benchmark.py:167-179 (xs = x*ry through MFMA, rank-1 corrections after).
- * workspace: mm8_seq_workspace_bytes(B, N, M) bytes of device scratch.
+ * Runs on the matrix cores: w is re-laid into K-contiguous tile images in the workspace (mm8_pack) and multiplied by
+ * mm8t_seq, i.e. binary32 accumulate in the algebraically split form of scripts/test_mm8/benchmark.py:167-179
+ * (xs = fp16(x*ry) through MFMA, rank-1 corrections after) -- the reference's own tolerance between its split and
+ * direct forms is rtol 1e-3 (benchmark_pure_pytorch.py:92).  Needs N % 64 == 0, M % 128 == 0, 16-byte aligned x / w and
+ * w_stride % 16 == 0; any other shape runs mm8_seq_direct.  Static weights: pack once with mm8_pack and call
+ * mm8t_seq(w_tiled = 1) directly (what chirrup_amd.ops.mm8_seq does behind a per-tensor cache).
+ * workspace: mm8_seq_workspace_bytes(B, N, M) bytes of device scratch (0 for the direct fallback).
  */
 int64_t mm8_seq_workspace_bytes(int B, int N, int M);
 int mm8_seq(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
             const void *mx, const void *rx, const void *my, const void *ry, void *y,
             int y_stride, void *workspace, void *stream);
+int mm8_seq_opt(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+                const void *mx, const void *rx, const void *my, const void *ry, void *y,
+                int y_stride, void *workspace, void *stream);
+/* The as-coded kernel (rwkv_pip_operators.cu:59-83): binary32 accumulate over j in order, one rounding per operation;
+ * bit-identical to oracle_mm8_seq.  Any shape; FP32 VALU, not MFMA -- parity and ragged shapes only. */
+int mm8_seq_direct(int B, int N, int M, const void *x, int x_stride, const void *w, int w_stride,
+                   const void *mx, const void *rx, const void *my, const void *ry, void *y,
+                   int y_stride, void *stream);
+/* w [N][M] uint8 (row stride w_stride, % 16 == 0; N % 64 == 0, M % 128 == 0) -> mm8_packed_bytes(N, M) = N*M bytes in the
+ * layout mm8t_seq(w_tiled = 1) reads: the transposed matrix wT [M][N] cut into 8-KiB (128 x 64) tile images. */
+int64_t mm8_packed_bytes(int N, int M);
+int mm8_pack(int N, int M, const void *w, int w_stride, void *packed, void *stream);
 
 /* GEMV form, binary32 output that the caller zeroes (the reference accumulates with
  * atomicAdd).  Replaces: rwkv_pip::mm8_one  scripts/test_mm8/rwkv_pip_wrapper.cpp:86-119

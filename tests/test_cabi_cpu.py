@@ -72,5 +72,5 @@ def test_torch_op_registration_uses_reference_names():
     ops.register_torch_ops()
     for name in ("forward_one", "forward_seq", "spmv_forward"):
         assert hasattr(torch.ops.rwkv7_state_fwd_fp16, name)
-    for name in ("mm8_seq", "mm8_one"):
+    for name in ("mm8_seq", "mm8_one", "mm8_seq_opt"):
         assert hasattr(torch.ops.rwkv_pip, name)

@@ -181,4 +181,4 @@ def test_prefill_chunk_equals_tokens_fed_one_at_a_time_at_production_width(big):
     e_shift = rel_linf(pool_a[0].cpu().numpy(), pool_b[0].cpu().numpy())
     e_lg = rel_linf(lg_a.cpu().numpy(), lg_b.cpu().numpy())
     print(f"chunk vs token-by-token: wkv {e_wkv:.2e} shift {e_shift:.2e} logits {e_lg:.2e}")
-    assert e_wkv <= 1e-2 and e_shift <= 1e-2 and e_lg <= 1e-2
+    assert e_wkv <= 4e-3 and e_shift <= 4e-3 and e_lg <= 4e-3      # measured 1.6e-3 / 1.2e-3 / 1.3e-3

@@ -58,11 +58,12 @@ def test_add_ln_mix(B, T, C, n_mix, with_delta):
     tx, tprev = cu(x), cu(prev)
     out = torch.empty((max(n_mix, 1), B, T, C), dtype=torch.float16, device="cuda")
     prev_out = tprev if T == 1 else torch.empty_like(tprev)
-    ops.add_ln_mix(B, T, C, tx, cu(delta) if with_delta else None, tx if with_delta else None, cu(w), cu(b), 1e-5,
+    x_new = tx if T == 1 else torch.empty_like(tx)       # in place only for T == 1 (T > 1: rows re-read their predecessor)
+    ops.add_ln_mix(B, T, C, tx, cu(delta) if with_delta else None, x_new if with_delta else None, cu(w), cu(b), 1e-5,
                    tprev if n_mix else None, prev_out if n_mix else None, cu(mix[:n_mix]) if n_mix else None, out)
     got = out.cpu().numpy()
     if with_delta:
-        assert np.array_equal(bits(tx.cpu().numpy()), bits(xn))          # residual add is exact
+        assert np.array_equal(bits(x_new.cpu().numpy()), bits(xn))       # residual add is exact
     # LN outputs reach |x| ~ 4-5 (ulp 3.9e-3); a one-ulp flip there can survive a cancelling lerp
     assert_close_ulps(got, want, 2, 0.02, "mixed", atol=4e-3)
     if n_mix:

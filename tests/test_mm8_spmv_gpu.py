@@ -29,9 +29,91 @@ def test_mm8_seq_direct_kernel_bit_exact(oracle, B, N, M):
     want = oracle.mm8_seq(x, w, mx, rx, my, ry)
     t = [torch.from_numpy(z).cuda() for z in (x, w, mx, rx, my, ry)]
     y = torch.empty((B, M), dtype=torch.float16, device="cuda")
-    ops.mm8_seq(B, N, M, *t, y)
+    ops.mm8_seq_direct(B, N, M, *t, y)
     got = y.cpu().numpy()
     assert np.array_equal(bits(got), bits(want)), f"{(bits(got) != bits(want)).sum()} of {got.size} differ"
+    if N % 64 or M % 128:        # shapes the packed layout cannot hold: the reference-named op runs this same kernel
+        y2 = torch.empty_like(y)
+        ops.mm8_seq(B, N, M, *t, y2)
+        assert torch.equal(y, y2)
+
+
+def _quantised_case(B, N, M, seed):
+    from oracle import rwkv7_np as M_
+
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, N)).astype(F16)
+    w16 = (rng.standard_normal((N, M)) / np.sqrt(N)).astype(F16)
+    q, mx, rx, my, ry = M_.quantize_weight(w16)
+    return x, q, mx, rx, my.reshape(-1), ry.reshape(-1)
+
+
+@pytest.mark.parametrize("B,N,M", [(4, 256, 512), (3, 512, 128), (200, 4096, 1024), (200, 1024, 4096), (600, 512, 256)])
+def test_mm8_seq_op_reaches_the_mfma_kernel(oracle, B, N, M):
+    """The reference-named operator (weights [N, M] uint8 row-major, rwkv_pip_wrapper.cpp:51-84) through the packed
+    MFMA path, three ways: the cached-pack op (torch.ops.rwkv_pip.mm8_seq and mm8_seq_opt), and the stateless C-ABI
+    entry that packs into its workspace on every call.  Bar: the reference's own tolerance between its split and
+    direct forms (rtol 1e-3, benchmark_pure_pytorch.py:92) doubled for the fp16 rounding of xs, against the row scale."""
+    from chirrup_amd import ops
+
+    ops.register_torch_ops()
+    x, q, mx, rx, my, ry = _quantised_case(B, N, M, seed=B + N + M)
+    want = oracle.mm8_seq(x, q, mx, rx, my.reshape(-1, 1), ry.reshape(-1, 1)).astype(np.float32)
+    t = [torch.from_numpy(z).cuda() for z in (x, q, mx, rx, my, ry)]
+    scale = np.abs(want).max()
+    outs = []
+    for fn in (torch.ops.rwkv_pip.mm8_seq, torch.ops.rwkv_pip.mm8_seq_opt, ops.mm8_seq_stateless):
+        y = torch.full((B, M), float("nan"), dtype=torch.float16, device="cuda")
+        fn(B, N, M, *t, y)
+        got = y.cpu().numpy().astype(np.float32)
+        assert np.allclose(got, want, rtol=2e-3, atol=2e-3 * scale), float(np.abs(got - want).max() / scale)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # same packed bytes, same kernel
+    # the pack is cached per weight tensor and follows in-place updates of it
+    n_entries = len(ops._MM8_PACK_CACHE)
+    y = torch.empty((B, M), dtype=torch.float16, device="cuda")
+    ops.mm8_seq(B, N, M, *t, y)
+    assert len(ops._MM8_PACK_CACHE) == n_entries and torch.equal(y, outs[0])
+    t[1].add_(1)                                                                  # wraps 255 -> 0: a different matrix
+    ops.mm8_seq(B, N, M, *t, y)
+    q2 = t[1].cpu().numpy()
+    want2 = oracle.mm8_seq(x, q2, mx, rx, my.reshape(-1, 1), ry.reshape(-1, 1)).astype(np.float32)
+    assert np.allclose(y.cpu().numpy().astype(np.float32), want2, rtol=2e-3, atol=2e-3 * np.abs(want2).max())
+
+
+def test_mm8_seq_op_at_the_ffn_key_shape_and_its_speed():
+    """(200, 4096, 16384) through the B1 op within rtol 2e-3 of the as-coded arithmetic (BLAS-summed
+    oracle, tests/test_oracle_cpu.py) and at least 5x faster than the scalar kernel there."""
+    from chirrup_amd import ops
+    from oracle import rwkv7_np as M_
+
+    B, N, M = 200, 4096, 16384
+    x, q, mx, rx, my, ry = _quantised_case(B, N, M, seed=1)
+    want = M_.mm8_seq_blas(x, q, mx, rx, my, ry).astype(np.float32)
+    t = [torch.from_numpy(z).cuda() for z in (x, q, mx, rx, my, ry)]
+    y, yd = (torch.empty((B, M), dtype=torch.float16, device="cuda") for _ in range(2))
+
+    def timed(fn, out, n):
+        fn(B, N, M, *t, out)                      # warm-up (packs the weight on the first cached call)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn(B, N, M, *t, out)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    t_mfma = timed(ops.mm8_seq, y, 10)
+    t_stateless = timed(ops.mm8_seq_stateless, y, 5)
+    t_direct = timed(ops.mm8_seq_direct, yd, 2)
+    got = y.cpu().numpy().astype(np.float32)
+    scale = np.abs(want).max()
+    assert np.allclose(got, want, rtol=2e-3, atol=2e-3 * scale), float(np.abs(got - want).max() / scale)
+    assert np.allclose(yd.cpu().numpy().astype(np.float32), want, rtol=1e-3, atol=1e-3 * scale)
+    print(f"mm8_seq (200,4096,16384): cached-pack MFMA {t_mfma * 1e3:.1f} us, pack-per-call {t_stateless * 1e3:.1f} us, "
+          f"as-coded scalar kernel {t_direct * 1e3:.1f} us")
+    assert t_direct >= 5 * t_mfma and t_direct >= 5 * t_stateless
 
 
 @pytest.mark.parametrize("N,M", [(64, 256), (300, 700), (1024, 4096)])
