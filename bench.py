@@ -43,7 +43,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
-    p.add_argument("--gemm-mode", type=int, default=None, help="skinny GEMM kernel variant (skinny_gemm_select), A/B only")
+    p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
     p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
@@ -266,9 +266,8 @@ def main():
     L, C = CONFIGS[a.model]
     B = a.bsz
     model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
-    if a.gemm_mode is not None:
-        from chirrup_amd import lib
-        lib.load().skinny_gemm_select(a.gemm_mode)
+    if a.splits is not None:
+        model.gemm_splits.update(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (int(v) for v in a.splits.split(","))))
     if a.skinny_key is not None:
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:

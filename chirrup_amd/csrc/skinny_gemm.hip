@@ -1,35 +1,40 @@
 // Skinny-M MFMA GEMMs for the decode step:  Y[M][N] = X[M][K] . W[N][K]^T   (M <= 256 token rows)
-// with binary16 or uint8 (mm8) weights, binary32 accumulation.  One RWKV-7 layer at 1..256 token rows runs five launches of
-// the ring kernel below: R/K/V + the four LoRA down-projections (grouped), the four LoRA up-projections (batched, per-
+// with binary16 or uint8 (mm8) weights, binary32 accumulation.  One RWKV-7 layer at 1..256 token rows runs five launches
+// of these kernels: R/K/V + the four LoRA down-projections (grouped), the four LoRA up-projections (batched, per-
 // problem reduction length), att.output, ffn.key, ffn.value (DESIGN.md sections 4-5 have the measurements).
 //
 // Why hand-written: at M = 200 the library GEMMs (hipBLASLt through torch) stream weights at 1.4-2.8 TB/s and every
-// projection is its own launch (or needs a side stream, whose graph edges cost ~19 us per layer).  Here the batch is
-// small enough that ONE workgroup holds all M rows of x for its K-block in LDS, and independent problems share a launch.
+// projection is its own launch.  Here the batch is small enough that ONE workgroup holds all M rows of x for its K-block
+// in LDS, and independent problems share a launch.  What bounds these kernels is the operand INGEST of a CU, not HBM
+// (profiles/r02_gemm_pmc_traffic.json: HBM bytes = algorithmic bytes, x re-reads are L2 hits): a CU takes in ~28 B/clk
+// through LDS-DMA whatever the source, and every workgroup needs all M rows of x beside its W tile.
 //
-// skinny_gemm_ring_kernel (what ships, variant 3 of skinny_gemm_select):
-//   * workgroup = 4 compute waves + 4 loader waves.  A 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA
-//     (global_load_lds_dwordx4) into a 3-slot ring: x image MT*32 rows x 128 B, W image 128 rows x 128 B (u8: 64 B),
-//     both XOR-swizzled on the SOURCE address so that the ds_read_b128 of the MFMA fragments are conflict-free.  No
-//     load of the main loop has a register destination, so one hand-placed `s_waitcnt vmcnt(n)` + raw `s_barrier`
-//     per K-block keeps two whole stages in flight.  The loader waves exist because a wave is blocked while its
-//     LDS-DMA instructions issue; the compute waves spend that time in MFMAs.
-//   * compute wave w owns 32 rows of W: v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m);
-//     one W fragment feeds MT = ceil(M/32) MFMAs (u8 -> f16 by v_perm in registers).  __builtin_amdgcn_sched_barrier
-//     pins "read the next MT x fragments, then MT MFMAs": left alone the scheduler sinks every ds_read to its MFMA.
-//   * split-K over blockIdx.y with binary32 partials; the partials are reduced by skinny_reduce_kernel (bias, relu^2,
-//     tanh / sigmoid of the LoRA planes, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179) or by
-//     the NEXT layer-norm kernel (rwkv7_add_ln_mix, delta_partials).
-//   * batched (gridDim.z problems at uniform strides, optional per-problem K) and grouped launches (per-problem
-//     operands, N and output stride; blockIdx.x runs over an exact tile list -- an empty workgroup would still have to
-//     be given its 132 KiB of LDS before it could leave).
-//   * workgroup -> tile order is XCD-aware (tile_of_block).
-// skinny_gemm_kernel is the first, register-staged design (variant 0), kept for A/B: W streamed HBM -> VGPRs, x through a
-// double-buffered LDS image.  Variants 1 and 2 are intermediate forms of the ring kernel (every wave loads; x / W loader
-// roles).  K is consumed in a permuted order inside each 64-block (lane half h takes k = 32h + 8s + j at MFMA step s)
-// -- the same permutation on both operands, so the dot products are unchanged.
+// Both kernels: a 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA (global_load_lds_dwordx4) into rings --
+// x image MT*32 rows x 128 B, W image BN rows x 128 B (u8: 64 B), XOR-swizzled on the SOURCE address so that the
+// ds_read_b128 of the MFMA fragments are conflict-free.  No load of the main loop has a register destination, so hand-
+// placed `s_waitcnt vmcnt(n)` + one raw `s_barrier` per K-block keep whole stages in flight across the barrier.
+// A compute wave owns 32 rows of W: v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m); one W
+// fragment feeds MT = ceil(M/32) MFMAs (u8 -> f16 by v_perm in registers).  K is consumed in a permuted order inside each
+// 64-block (lane half h takes k = 32h + 8s + j at MFMA step s) -- the same permutation on both operands.
+//
+// wide_gemm_kernel (BN = 256): 8 compute waves, two per SIMD; waves 0-3 also issue the x loads of the NEXT K-block
+//     (L2-resident, 2 slots) at the start of an iteration, waves 4-7 the W loads two K-blocks ahead (HBM, `nt`, 3 slots)
+//     in the MIDDLE of theirs -- a wave is blocked while its LDS-DMA instructions issue, and this way its SIMD partner
+//     has MFMAs to run meanwhile; vmcnt retires in order per wave, so the split also keeps the x wait from waiting on W.
+//     Per W byte a workgroup ingests 0.875 B of x (224 x 128 B per 256 x 128 B) instead of 1.75 B at BN = 128.
+// ring_gemm_kernel (BN = 128): 4 compute + 4 dedicated loader waves, one 3-slot ring for both operands (round 1's
+//     kernel).  Kept for the narrow problems (LoRA ranks, N < 256) and as the A/B partner (CHIRRUP_GEMM_BN=128|256).
+//
+// Common: split-K over blockIdx.y with binary32 partials, reduced by skinny_reduce_kernel (bias, relu^2, tanh / sigmoid
+// of the LoRA planes, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179) or by the NEXT layer-norm
+// kernel (rwkv7_add_ln_mix, delta_partials); batched (gridDim.z problems at uniform strides, optional per-problem K) and
+// grouped launches (per-problem operands, N and output stride; blockIdx.x runs over an exact tile list -- an empty
+// workgroup would still have to be given its LDS before it could leave); workgroup -> tile order is XCD-aware.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "../../include/chirrup_amd.h"
 
@@ -48,8 +53,7 @@ typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 constexpr int kKB = 64;          // K-block
-constexpr int kThreads = 256;    // 4 waves
-constexpr int kBN = 128;         // output columns per workgroup
+constexpr int kTileRows = 128;   // rows of one tile image (skinny_tile_weight): both kernels stage whole 128-row tiles
 
 enum { EPI_F16 = 0, EPI_PARTIAL = 1 };
 
@@ -64,12 +68,6 @@ __device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
     const f16x2 off = {(f16)1024.f, (f16)1024.f};
     return v - off;
 }
-
-// Raw weight bytes of one K-block for one lane (k = k0 + 32h .. +32): 64 B (f16) or 32 B (u8).
-template <bool W8>
-struct WRaw {
-    u32x4 q[W8 ? 2 : 4];
-};
 
 // Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
 // own L2: give XCD j a contiguous run of the K-slice-major tile order, so the x K-slice a workgroup re-reads is shared
@@ -106,161 +104,13 @@ struct GroupTable {
     int used;                      // an empty one would still wait for its 132 KiB of LDS before it could leave
 };
 
-template <int MT, bool W8, int EPI>
-__global__ __launch_bounds__(kThreads) void skinny_gemm_kernel(
-    const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
-    const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
-    const f16 *__restrict__ bias, float *__restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x MT x 4 KiB
-    constexpr int kTileBytes = MT * 32 * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    int ngroup, kslice, batch_unused;
-    tile_of_block(ngroup, kslice, batch_unused);
-    const int n0 = (ngroup * 4 + wave) * 32;
-    const bool wave_live = n0 < N;
-    const int k_begin = kslice * k_slice;
-    const int k_end = (k_begin + k_slice) < K ? (k_begin + k_slice) : K;
-    const int nkb = (k_end - k_begin) / kKB;
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
-
-    // x K-block: MT 16-B chunks per lane.  Chunk g = i*256 + tid lands at LDS byte g*16 (linear,
-    // conflict-free ds_write_b128); WHICH chunk of x that is is permuted on the source side so that
-    // chunk c of row m sits at m*128 + ((c ^ ((m>>1)&7))<<4) for the B-fragment reads.
-    const f16 *xsrc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
-        const int g = i * kThreads + tid;
-        int m = g >> 3;
-        const int lc = (g & 7) ^ ((m >> 1) & 7);
-        m = m < M ? m : M - 1;
-        xsrc[i] = X + (int64_t)m * ldx + k_begin + lc * 8;
-    }
-    auto load_x = [&](int kb, u32x4 (&xr)[MT]) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) xr[i] = *reinterpret_cast<const u32x4 *>(xsrc[i] + kb * kKB);
-    };
-    auto store_x = [&](int buf, const u32x4 (&xr)[MT]) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) *reinterpret_cast<u32x4 *>(smem + buf * kTileBytes + (i * kThreads + tid) * 16) = xr[i];
-    };
-    const int n_row = (n0 + r) < N ? (n0 + r) : (N - 1);
-    const unsigned char *wrow = static_cast<const unsigned char *>(Wv) + ((int64_t)n_row * ldw + k_begin + 32 * h) * (W8 ? 1 : 2);
-    auto load_w = [&](int kb, WRaw<W8> &w) {
-        const u32x4 *p = reinterpret_cast<const u32x4 *>(wrow + (int64_t)kb * kKB * (W8 ? 1 : 2));
-#pragma unroll
-        for (int i = 0; i < (W8 ? 2 : 4); i++) w.q[i] = p[i];
-    };
-
-    auto compute = [&](int buf, const WRaw<W8> &w) {
-        f16x8 wf[4];
-        if constexpr (W8) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const uint32_t lo = w.q[s >> 1][2 * (s & 1)], hi = w.q[s >> 1][2 * (s & 1) + 1];
-                const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
-                wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; s++) wf[s] = __builtin_bit_cast(f16x8, w.q[s]);
-        }
-        const unsigned char *xt = smem + buf * kTileBytes;
-        auto bfrag = [&](int s, int mt) {
-            const int m = mt * 32 + r;
-            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
-        };
-        // B fragments one MFMA group ahead of their use (two register sets of MT fragments)
-        f16x8 b0[MT], b1[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(0, mt);
-#pragma unroll
-        for (int s = 0; s < 4; s += 2) {
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) b1[mt] = bfrag(s + 1, mt);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], b0[mt], acc[mt], 0, 0, 0);
-            if (s + 2 < 4) {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) b0[mt] = bfrag(s + 2, mt);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s + 1], b1[mt], acc[mt], 0, 0, 0);
-        }
-    };
-
-    // Everything is visible to hipcc (no LDS-DMA, no asm): its counted vmcnt waits keep the W loads
-    // of the next two K-blocks and the x loads of the next one in flight across __syncthreads()
-    // (a plain s_barrier when no LDS-DMA is pending).
-    WRaw<W8> w0, w1, w2;
-    u32x4 xr[MT];
-    if (nkb > 0) {
-        load_x(0, xr);
-        load_w(0, w0);
-        if (nkb > 1) load_w(1, w1);
-        store_x(0, xr);
-    }
-    __syncthreads();
-#define SKINNY_STEP(KB, WCUR, WNEXT2)                                   \
-    if ((KB) < nkb) {                                                   \
-        const bool more = (KB) + 1 < nkb;                               \
-        if (more) load_x((KB) + 1, xr);                                 \
-        if ((KB) + 2 < nkb) load_w((KB) + 2, WNEXT2);                   \
-        compute((KB) & 1, WCUR);                                        \
-        if (more) store_x(((KB) + 1) & 1, xr);                          \
-        __syncthreads();                                                \
-    }
-    for (int kb = 0; kb < nkb; kb += 3) {
-        SKINNY_STEP(kb, w0, w2)
-        SKINNY_STEP(kb + 1, w1, w0)
-        SKINNY_STEP(kb + 2, w2, w1)
-    }
-#undef SKINNY_STEP
-
-    if (!wave_live) return;
-    // acc[mt][i]: m = mt*32 + (lane & 31), n = n0 + 8*(i>>2) + 4*h + (i&3)
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int m = mt * 32 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int n = n0 + 8 * g + 4 * h;
-            if (n >= N) continue;
-            if (EPI == EPI_F16) {
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    float v = acc[mt][4 * g + e];
-                    if (bias) v += (float)bias[n + e];
-                    o[e] = (f16)v;
-                }
-                *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
-            } else {
-                const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * N + n) = o;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring variant (binary16 weights): BOTH operands reach LDS by LDS-DMA into a 3-deep ring, so no load
-// of the main loop has a register destination -- hipcc inserts no vmcnt wait of its own, and the
-// hand-placed counted waits keep two whole K-blocks (2 x 44 KiB at M = 200) in flight per workgroup
-// across raw barriers.  Same tiles, swizzle and MFMA schedule as above; W fragments are read from
-// the ring like the x fragments.
-// s_waitcnt vmcnt(ahead * PER): leave the `ahead` youngest stages (PER LDS-DMA instructions each) in flight
+// s_waitcnt vmcnt(ahead * PER): leave the `ahead` youngest stages (PER LDS-DMA instructions each) in flight.  The
+// counter field holds 0..63: a count that does not fit waits for fewer outstanding loads, which is always safe.
 template <int PER>
 __device__ __forceinline__ void wait_stages_ahead(const int ahead) {
-#define WAIT_CASE(A)                                                                  \
-    case A:                                                                           \
-        if constexpr ((A) * PER <= 63) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * PER) : "memory"); \
+#define WAIT_CASE(A)                                                                                            \
+    case A:                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * PER <= 63 ? (A) * PER : (63 / PER) * PER) : "memory"); \
         break;
     switch (ahead) {
         WAIT_CASE(7) WAIT_CASE(6) WAIT_CASE(5) WAIT_CASE(4) WAIT_CASE(3) WAIT_CASE(2) WAIT_CASE(1)
@@ -269,57 +119,167 @@ __device__ __forceinline__ void wait_stages_ahead(const int ahead) {
 #undef WAIT_CASE
 }
 
-// Both operands through LDS-DMA rings; four waves compute (32 W rows x MT*32 x rows each).  Who issues the loads (RM):
-//   0: every compute wave loads its share of x and W; one ring of XD (== WD) slots.
-//   1: waves 0-1 load x (L2-resident, XD slots), waves 2-3 load W (HBM, WD slots): vmcnt counts per wave and retires
-//      in order, so only a wave that issues nothing but W loads can keep WD-1 weight stages in flight without also
-//      waiting for the x stage issued after them.
-//   2: four extra loader waves (one per SIMD, 512-thread workgroup) issue everything: a wave is blocked while its
-//      LDS-DMA instructions issue (~0.15 us per 16 KiB), which the compute waves then spend in MFMAs instead.
-template <int MT, bool W8, int EPI, int XD, int WD, int RM>
-__global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_kernel(
+// W slots of the BN = 128 kernel: what fits in the 160 KiB of LDS beside the two x slots, at most 8 (vmcnt holds 63).
+// What one workgroup works on, resolved from the launch arguments (plain / batched / grouped launch).
+struct Tile {
+    const f16 *X;
+    const void *W;
+    f16 *Y;
+    const f16 *bias;
+    float *part;
+    int Np, ldy, ngroup, kslice, batch;
+    bool w_tiled;
+};
+
+template <bool W8>
+__device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const void *Wv, f16 *Y, const int ldy, const f16 *bias,
+                                             float *part, const int M, const BatchStrides &bs, const GroupTable &gt) {
+    Tile t;
+    tile_of_block(t.ngroup, t.kslice, t.batch);
+    t.X = X, t.W = Wv, t.Y = Y, t.bias = bias, t.part = part, t.Np = N, t.ldy = ldy, t.w_tiled = bs.tiled != 0;
+    if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
+        int b = 0;
+        while (b + 1 < gt.used && t.ngroup >= gt.first[b + 1]) b++;
+        t.batch = b;
+        t.ngroup -= gt.first[b];
+        t.X = gt.X[b], t.W = gt.W[b], t.Y = gt.Y[b], t.bias = gt.bias[b], t.part = gt.part[b];
+        t.Np = gt.N[b], t.ldy = gt.ldy[b];
+        t.w_tiled = gt.tiled[b] != 0;
+    } else {
+        t.X += t.batch * bs.x;
+        t.W = static_cast<const unsigned char *>(Wv) + t.batch * bs.w * (W8 ? 1 : 2);
+        if (Y) t.Y += t.batch * bs.y;
+        if (bias) t.bias += t.batch * bs.bias;
+        if (part) t.part += (int64_t)t.batch * gridDim.y * M * N;
+    }
+    return t;
+}
+
+// One LDS-DMA instruction (1 KiB per wave) of a W tile image: chunk gi (0 .. 1023 for binary16, 0 .. 511 for uint8) of the
+// 128-row tile `tile_row0 / 128` at K-block k0 / 64, to the wave-uniform LDS address dst (+ lane * 16 by the hardware).
+// Tile-image weights: the image is stored contiguously in LDS order, so the instruction reads 1 KiB of consecutive
+// memory; row-major weights: eight (four) 128-B (64-B) pieces of rows ldw apart, chunk order permuted on the source.
+template <bool W8>
+__device__ __forceinline__ void glds_w_chunk(const void *W, const bool w_tiled, const int64_t ldw, const int K, const int Np,
+                                             const int tile_row0, const int k0, const int gi, unsigned char *dst) {
+    if constexpr (W8) {                                // 64-B rows: 4 chunks per row, chunk position ^ ((row>>2)&3)
+        const int nr = gi >> 2;
+        const int lc = (gi & 3) ^ ((nr >> 2) & 3);
+        int n = tile_row0 + nr;
+        n = n < Np ? n : Np - 1;
+        const int tr = tile_row0 < Np ? tile_row0 : 0;       // (a 256-wide group whose second tile does not exist re-reads tile 0)
+        const uint8_t *src = w_tiled ? static_cast<const uint8_t *>(W) + ((int64_t)(tr / kTileRows) * (K / kKB) + k0 / kKB) * (kTileRows * kKB) + gi * 16
+                                     : static_cast<const uint8_t *>(W) + (int64_t)n * ldw + k0 + lc * 16;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 2);           // streamed once -> nt
+    } else {
+        const int nr = gi >> 3;
+        const int lc = (gi & 7) ^ ((nr >> 1) & 7);
+        int n = tile_row0 + nr;
+        n = n < Np ? n : Np - 1;
+        const int tr = tile_row0 < Np ? tile_row0 : 0;
+        const f16 *src = w_tiled ? static_cast<const f16 *>(W) + ((int64_t)(tr / kTileRows) * (K / kKB) + k0 / kKB) * (kTileRows * kKB) + gi * 8
+                                 : static_cast<const f16 *>(W) + (int64_t)n * ldw + k0 + lc * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 2);
+    }
+}
+
+// The four W fragments (k steps) of lane (r, h) for in-tile row `row` of the tile image at wt.
+template <bool W8>
+__device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int row, const int h, f16x8 (&wf)[4]) {
+    if constexpr (W8) {
+        // lane (r,h) needs bytes 32h .. 32h+31 of its row: chunks 2h and 2h+1
+        const int sw = (row >> 2) & 3;
+        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(wt + row * 64 + (((2 * h) ^ sw) << 4));
+        const u32x4 q1 = *reinterpret_cast<const u32x4 *>(wt + row * 64 + (((2 * h + 1) ^ sw) << 4));
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint32_t lo = s < 2 ? q0[2 * s] : q1[2 * (s - 2)];
+            const uint32_t hi = s < 2 ? q0[2 * s + 1] : q1[2 * (s - 2) + 1];
+            const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
+            wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + row * 128 + (((4 * h + s) ^ ((row >> 1) & 7)) << 4));
+    }
+}
+
+// Epilogue shared by both kernels: `stage` holds rows m of 128 binary32 columns (kLd floats apart); the threads of the
+// workgroup store them as whole 512-B (f16: 256-B) row pieces.  Straight from the MFMA layout every store instruction
+// would touch 32 rows x 32 B (measured: ~8 us per launch of scattered stores).
+constexpr int kLd = kTileRows + 4;                     // floats per staged row: rows shift by 16 B -> conflict-free b128 writes
+template <int EPI, int THREADS>
+__device__ __forceinline__ void store_staged(const float *stage, const int M, const int n_first, const Tile &t, const int kslice,
+                                             const int relu_sq) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31;                           // 4 columns per lane, 32 lanes per row, THREADS/32 rows per pass
+    const int n = n_first + 4 * c4;
+    if (n >= t.Np) return;
+    for (int m = tid >> 5; m < M; m += THREADS / 32) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 4 * c4);
+        if (EPI == EPI_F16) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float x = t.bias ? v[e] + (float)t.bias[n + e] : v[e];
+                if (relu_sq) {
+                    x = (float)(f16)x;               // relu(fp16(y))**2, rwkv7.py:678
+                    x = x > 0.f ? x * x : 0.f;
+                }
+                o[e] = (f16)x;
+            }
+            *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
+        } else {
+            *reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * M + m) * t.Np + n) = v;
+        }
+    }
+}
+
+// acc[mt][i] of the wave that owns staged columns col0 .. col0+31: m = mt*32 + (lane & 31), n = col0 + 8*(i>>2) + 4*h + (i&3)
+template <int MT>
+__device__ __forceinline__ void stage_acc(float *stage, const f32x16 (&acc)[MT], const int M, const int col0, const int r, const int h) {
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int m = mt * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+            *reinterpret_cast<f32x4 *>(stage + m * kLd + col0 + 8 * g + 4 * h) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN = 128: four compute waves + four dedicated loader waves, one ring of D slots for both operands (each loader wave
+// issues its quarter of the x and of the W stage and waits for it with one counted vmcnt).
+// (Measured and dropped, profiles/r02_gemm_experiments.txt: x and W loader roles on two waves each with a deeper W ring
+// -- 6x slower, a loader wave that has to wait for its whole x stage every K-block is the critical path.)
+template <int MT, bool W8, int EPI>
+__global__ __launch_bounds__(512) void ring_gemm_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
     const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
     const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
-    static_assert(RM == 1 || XD == WD, "one ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BN = 128, D = W8 ? 4 : 3;
     constexpr int kXBytes = MT * 32 * 128;            // x K-block image
-    constexpr int kWBytes = kBN * (W8 ? 64 : 128);    // W K-block image: 128 rows x 64 k (binary16 or uint8)
-    constexpr int kLanes = RM == 1 ? 128 : 256;       // lanes that load one operand
-    constexpr int kXLoads = kXBytes / 16 / kLanes;    // LDS-DMA instructions per loading lane per stage
-    constexpr int kWLoads = kWBytes / 16 / kLanes;
+    constexpr int kWBytes = BN * (W8 ? 64 : 128);     // W K-block image: 128 rows x 64 k (binary16 or uint8)
+    constexpr int kXLoads = kXBytes / 16 / 256;       // LDS-DMA instructions per loader lane per stage
+    constexpr int kWLoads = kWBytes / 16 / 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const bool computes = wave < 4;
-    const bool loads_x = RM == 0 || (RM == 1 ? wave < 2 : wave >= 4), loads_w = RM == 0 || (RM == 1 ? wave >= 2 : wave >= 4);
-    const int lt = RM == 1 ? (tid & 127) : (tid & 255), lw = RM == 1 ? (wave & 1) : (wave & 3);
-    int ngroup, kslice, batch;
-    tile_of_block(ngroup, kslice, batch);
-    int Np = N, ldyp = ldy;
-    bool w_tiled = bs.tiled != 0;
-    if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
-        batch = 0;
-        while (batch + 1 < gt.used && ngroup >= gt.first[batch + 1]) batch++;
-        ngroup -= gt.first[batch];
-        X = gt.X[batch], Wv = gt.W[batch], Y = gt.Y[batch], bias = gt.bias[batch], part = gt.part[batch];
-        Np = gt.N[batch], ldyp = gt.ldy[batch];
-        w_tiled = gt.tiled[batch] != 0;
-    } else {
-        X += batch * bs.x;
-        Wv = static_cast<const unsigned char *>(Wv) + batch * bs.w * (W8 ? 1 : 2);
-        if (Y) Y += batch * bs.y;
-        if (bias) bias += batch * bs.bias;
-        if (part) part += (int64_t)batch * gridDim.y * M * N;
-    }
-    const int n_base = ngroup * kBN;
+    const int lt = tid & 255, lw = wave & 3;
+    const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
+    const int n_base = t.ngroup * BN;
     const int n0 = n_base + wave * 32;
-    const bool wave_live = computes && n0 < Np;
-    const int k_begin = kslice * k_slice;
-    const int Kz = (batch < 8 && bs.k[batch] > 0) ? bs.k[batch] : K;
+    const bool wave_live = computes && n0 < t.Np;
+    const int k_begin = t.kslice * k_slice;
+    const int Kz = (t.batch < 8 && bs.k[t.batch] > 0) ? bs.k[t.batch] : K;
     const int k_end = (k_begin + k_slice) < Kz ? (k_begin + k_slice) : Kz;
     const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
-    unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
+    unsigned char *const xring = smem, *const wring = smem + D * kXBytes;
 
     f32x16 acc[MT];
 #pragma unroll
@@ -327,79 +287,29 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
 
-#ifndef SKINNY_EXP
-#define SKINNY_EXP 0   // ingest experiments (tools/exp_skinny_ingest.py): 1/2 = W / x always from the slice's first K-block,
-#endif                 // 4 = fragments fetched but no MFMA
-    auto stage_x = [&](int kb) {
-        const int k0 = k_begin + ((SKINNY_EXP & 2) ? 0 : kb * kKB);
-        unsigned char *base = xring + (kb % XD) * kXBytes;
+    auto stage = [&](int kb) {
+        const int k0 = k_begin + kb * kKB;
+        unsigned char *xb = xring + (kb % D) * kXBytes, *wb = wring + (kb % D) * kWBytes;
 #pragma unroll
         for (int i = 0; i < kXLoads; i++) {
-            const int g = i * kLanes + lt;
+            const int g = i * 256 + lt;
             int m = g >> 3;
             const int lc = (g & 7) ^ ((m >> 1) & 7);
             m = m < M ? m : M - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(X + (int64_t)m * ldx + k0 + lc * 8),
-                                             (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(t.X + (int64_t)m * ldx + k0 + lc * 8), (lptr_t)(xb + (i * 256 + lw * 64) * 16), 16, 0, 0);
         }
-    };
-    auto stage_w = [&](int kb) {                       // weights: streamed once -> nt
-        const int k0 = k_begin + ((SKINNY_EXP & 1) ? 0 : kb * kKB);
-        unsigned char *base = wring + (kb % WD) * kWBytes;
 #pragma unroll
-        for (int i = 0; i < kWLoads; i++) {
-            const int g = i * kLanes + lt;
-            if constexpr (W8) {                        // 64-B rows: 4 chunks per row, chunk position ^ ((row>>2)&3)
-                const int nr = g >> 2;
-                const int lc = (g & 3) ^ ((nr >> 2) & 3);
-                int n = n_base + nr;
-                n = n < Np ? n : Np - 1;
-                const uint8_t *src = w_tiled ? static_cast<const uint8_t *>(Wv) + ((int64_t)ngroup * (K / kKB) + k0 / kKB) * (kBN * kKB) + g * 16
-                                             : static_cast<const uint8_t *>(Wv) + (int64_t)n * ldw + k0 + lc * 16;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
-            } else {
-                const int nr = g >> 3;
-                const int lc = (g & 7) ^ ((nr >> 1) & 7);
-                int n = n_base + nr;
-                n = n < Np ? n : Np - 1;
-                // tile-image layout: the 16 KiB image of (N-group, K-block) is stored contiguously in LDS order, so a
-                // wave-instruction reads 1 KiB of consecutive bytes instead of eight 128-B pieces of eight rows
-                const f16 *src = w_tiled ? static_cast<const f16 *>(Wv) + ((int64_t)ngroup * (K / kKB) + k0 / kKB) * (kBN * kKB) + g * 8
-                                         : static_cast<const f16 *>(Wv) + (int64_t)n * ldw + k0 + lc * 8;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(base + (i * kLanes + lw * 64) * 16), 16, 0, 2);
-            }
-        }
+        for (int i = 0; i < kWLoads; i++)
+            glds_w_chunk<W8>(t.W, t.w_tiled, ldw, K, t.Np, n_base, k0, i * 256 + lt, wb + (i * 256 + lw * 64) * 16);
     };
     auto compute = [&](int kb) {
-        const unsigned char *xt = xring + (kb % XD) * kXBytes;
-        const unsigned char *wt = wring + (kb % WD) * kWBytes;
-        const int wr = wave * 32 + r;
+        const unsigned char *xt = xring + (kb % D) * kXBytes;
         f16x8 wf[4];
-        if constexpr (W8) {
-            // lane (r,h) needs bytes 32h .. 32h+31 of its row: chunks 2h and 2h+1
-            const int sw = (wr >> 2) & 3;
-            const u32x4 q0 = *reinterpret_cast<const u32x4 *>(wt + wr * 64 + (((2 * h) ^ sw) << 4));
-            const u32x4 q1 = *reinterpret_cast<const u32x4 *>(wt + wr * 64 + (((2 * h + 1) ^ sw) << 4));
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const uint32_t lo = s < 2 ? q0[2 * s] : q1[2 * (s - 2)];
-                const uint32_t hi = s < 2 ? q0[2 * s + 1] : q1[2 * (s - 2) + 1];
-                const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
-                wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + wr * 128 + (((4 * h + s) ^ ((wr >> 1) & 7)) << 4));
-        }
+        read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32 + r, h, wf);
         auto bfrag = [&](int s, int mt) {
             const int m = mt * 32 + r;
             return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
         };
-#if SKINNY_EXP & 4
-#define MMA(A, B, C) asm volatile("" ::"v"(A), "v"(B))   // exp 4: fragments fetched, no MFMA
-#else
-#define MMA(A, B, C) C = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0)
-#endif
         // x fragments one MFMA group ahead of their use.  The sched_barriers pin that order: left alone, the scheduler
         // sinks every ds_read to just before its MFMA (fewer live registers) and each MFMA then waits a full LDS latency.
         f16x8 bq[2][MT];
@@ -413,87 +323,210 @@ __global__ __launch_bounds__(RM == 2 ? 512 : kThreads) void skinny_gemm_ring_ker
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) MMA(wf[s], bq[s & 1][mt], acc[mt]);
+            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], bq[s & 1][mt], acc[mt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-#undef MMA
     };
 
-    // at step kb the x queue holds stages kb .. kb+XD-2 and the W queue kb .. kb+WD-2, each in issue order
+    // at step kb the ring holds stages kb .. kb+D-2, in issue order
+    if (!computes) {
 #pragma unroll
-    for (int p = 0; p < (XD > WD ? XD : WD) - 1; p++) {
-        if (loads_x && p < XD - 1 && p < nkb) stage_x(p);
-        if (loads_w && p < WD - 1 && p < nkb) stage_w(p);
+        for (int p = 0; p < D - 1; p++)
+            if (p < nkb) stage(p);
     }
     for (int kb = 0; kb < nkb; kb++) {
         const int left = nkb - 1 - kb;
-        const int ax = left < XD - 2 ? left : XD - 2, aw = left < WD - 2 ? left : WD - 2;   // younger stages already issued
-        if constexpr (RM == 0) wait_stages_ahead<kXLoads + kWLoads>(ax);
-        else if constexpr (RM == 2) { if (!computes) wait_stages_ahead<kXLoads + kWLoads>(ax); }
-        else if (loads_x) wait_stages_ahead<kXLoads>(ax);
-        else wait_stages_ahead<kWLoads>(aw);
-        asm volatile("s_barrier" ::: "memory");        // every wave's share landed; the slots restaged below are no longer read
-        if (loads_x && kb + XD - 1 < nkb) stage_x(kb + XD - 1);
-        if (loads_w && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
-        if (RM != 2 || computes) compute(kb);
+        if (!computes) wait_stages_ahead<kXLoads + kWLoads>(left < D - 2 ? left : D - 2);
+        asm volatile("s_barrier" ::: "memory");        // every loader's share landed; the slot restaged below is no longer read
+        if (!computes) {
+            if (kb + D - 1 < nkb) stage(kb + D - 1);
+        } else {
+            compute(kb);
+        }
     }
-
-    // ---- epilogue: accumulators -> LDS (row-major, 16-B shift per row) -> stores of whole 512-B (f16: 256-B) row pieces.
-    // Straight from the MFMA layout every store instruction would touch 32 rows x 32 B; measured on the decode step,
-    // those scattered stores cost ~8 us per launch (SKINNY_EXP 64: 8.00 -> 6.62 ms/step without them).
     if (!computes) return;                             // loader waves are done; finished waves do not count in s_barrier
-    if ((SKINNY_EXP & 64) && M > 1) {                  // exp 64: no epilogue stores (every accumulator stays live)
-        float t = 0.f;
+    float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*32 rows x 528 B <= its size)
+    __syncthreads();                                   // every compute wave is past its last fragment read
+    if (wave_live) stage_acc<MT>(stg, acc, M, wave * 32, r, h);
+    __syncthreads();
+    store_staged<EPI, 256>(stg, M, n_base, t, t.kslice, bs.relu_sq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN = 256: eight compute waves (two per SIMD).  Waves 0-3 issue the x loads (next K-block, 2 slots) at the start of an
+// iteration, waves 4-7 the W loads (WD-1 K-blocks ahead, WD slots) between the two halves of their MFMAs.
+// The loads are `buffer_load_dwordx4 ... lds` (LDS-DMA through a buffer descriptor): one 32-bit lane offset per role for the
+// whole kernel, everything that changes per instruction in the scalar offset -- the wave carries 7-8 accumulator tiles and
+// has no registers to spare for 64-bit addresses -- and rows past the end of an operand read as zeros (descriptor bounds)
+// instead of needing a clamp.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes < 0xffffffffll ? (int)bytes : (int)0xffffffff, 0x00020000);
+}
+
+template <int MT, bool W8, int EPI>
+__global__ __launch_bounds__(512) void wide_gemm_kernel(
+    const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
+    const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
+    const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifndef WIDE_WD
+#define WIDE_WD 3              // tools/ builds vary the W ring depth and where the W loads are issued
+#endif
+#ifndef WIDE_W_ISSUE_STEP
+#define WIDE_W_ISSUE_STEP 2
+#endif
+#ifndef WIDE_EXP
+#define WIDE_EXP 0             // timing experiments: 1 no MFMA (fragments still read), 2 no fragment reads either, 4 no loads, 8 no epilogue
+#endif
+    constexpr int BN = 256, XD = 2, WD = W8 ? 5 : WIDE_WD;
+    constexpr int kEl = W8 ? 1 : 2;                    // bytes per weight element
+    constexpr int kXBytes = MT * 32 * 128;
+    constexpr int kWTile = kTileRows * kKB * kEl;      // one 128-row tile image: 16 KiB (uint8: 8 KiB)
+    constexpr int kWBytes = 2 * kWTile;
+    constexpr int kXLoads = MT;                        // per x-loader wave: 4 waves x 1 KiB per round
+    constexpr int kWLoads = kWBytes / 16 / 256;        // per W-loader wave: 8 (uint8: 4)
+    constexpr int kPerTile = kWLoads / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const bool xrole = wave < 4;
+    const int lt = tid & 255, lw = wave & 3;
+    const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
+    const int n_base = t.ngroup * BN;
+    const int n0 = n_base + wave * 32;
+    const bool wave_live = n0 < t.Np;
+    const int k_begin = t.kslice * k_slice;
+    const int Kz = (t.batch < 8 && bs.k[t.batch] > 0) ? bs.k[t.batch] : K;
+    const int k_end = (k_begin + k_slice) < Kz ? (k_begin + k_slice) : Kz;
+    const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
+    unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
+
+    // x: chunk g = i*256 + lt of the image is row m = g >> 3 (= 32 i + (lt >> 3)), logical 16-B chunk (g & 7) ^ ((m >> 1) & 7)
+    // -- the XOR term does not depend on i, so round i is round 0 plus 32 rows.
+    const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(t.X, (int64_t)M * ldx * 2);
+    const int xoff = ((lt >> 3) * ldx + (((lt & 7) ^ ((lt >> 4) & 7)) << 3)) * 2;
+    // W: tile images are read linearly; row-major rows like x (uint8: 4 chunks per 64-B row, XOR ((row >> 2) & 3))
+    const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(t.W, t.w_tiled ? (int64_t)t.Np * K * kEl : (int64_t)t.Np * ldw * kEl);
+    const int wrow = W8 ? (lt >> 2) : (lt >> 3);
+    const int wlc = W8 ? ((lt & 3) ^ ((wrow >> 2) & 3)) : ((lt & 7) ^ ((wrow >> 1) & 7));
+    const int woff = t.w_tiled ? lt * 16 : (int)((wrow * ldw) * kEl + wlc * 16);
+    const int rows_per_round = W8 ? 64 : 32;           // rows of a tile image that one round of 256 lanes covers
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+#if WIDE_EXP & 16      // clock stamps (shader cycles / 100 MHz ticks) around the main loop, into plane 15 of the partial buffer
+    const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    auto stage_x = [&](int kb) {
+        const int k0 = k_begin + kb * kKB;
+        unsigned char *xb = xring + (kb % XD) * kXBytes;
+#pragma unroll
+        for (int i = 0; i < kXLoads; i++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)(xb + (i * 256 + lw * 64) * 16), 16, xoff, (i * 32 * ldx + k0) * 2, 0, 0);
+    };
+    auto stage_w = [&](int kb) {                       // streamed once -> nt
+        const int k0 = k_begin + kb * kKB;
+        unsigned char *wb = wring + (kb % WD) * kWBytes;
+#pragma unroll
+        for (int i = 0; i < kWLoads; i++) {
+            const int tile = i / kPerTile, round = i % kPerTile;
+            int row0 = n_base + tile * kTileRows;
+            unsigned soff;
+            if (t.w_tiled) {
+                if (row0 >= t.Np) row0 = n_base;       // a 256-wide group whose second tile does not exist re-reads the first
+                soff = (unsigned)(((row0 / kTileRows) * (K / kKB) + k0 / kKB) * kWTile + round * 4096);
+            } else {
+                soff = (unsigned)(((int64_t)(row0 + round * rows_per_round) * ldw + k0) * kEl);
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)(wb + (i * 256 + lw * 64) * 16), 16, woff, (int)soff, 0, 2);
+        }
+    };
+
+    // at step kb: the x ring holds stage kb, the W ring stages kb .. kb+WD-2, each in issue order of its loader waves
+    if (WIDE_EXP & 4) {
+    } else if (xrole) {
+        if (nkb > 0) stage_x(0);
+    } else {
+#pragma unroll
+        for (int p = 0; p < WD - 1; p++)
+            if (p < nkb) stage_w(p);
+    }
+    for (int kb = 0; kb < nkb; kb++) {
+        const int left = nkb - 1 - kb;
+        if (xrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_stages_ahead<kWLoads>(left < WD - 2 ? left : WD - 2);
+        asm volatile("s_barrier" ::: "memory");        // stage kb of both operands landed; the slots restaged below are no longer read
+        if (!(WIDE_EXP & 4) && xrole && kb + 1 < nkb) stage_x(kb + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (WIDE_EXP & 2) {
+            if (!(WIDE_EXP & 4) && !xrole && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
+            continue;
+        }
+        const unsigned char *xt = xring + (kb % XD) * kXBytes;
+        f16x8 wf[4];
+        read_w_frags<W8>(wring + (kb % WD) * kWBytes + (wave >> 2) * kWTile, (wave & 3) * 32 + r, h, wf);
+        auto bfrag = [&](int s, int mt) {
+            const int m = mt * 32 + r;
+            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
+        };
+        // x fragments one MFMA group ahead of their use (pinned with sched_barrier: left alone, the scheduler sinks every
+        // ds_read to just before its MFMA and each MFMA then waits a full LDS latency)
+        f16x8 bq[2][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) bq[0][mt] = bfrag(0, (WIDE_EXP & 32) ? (mt & ~1) : mt);   // exp 32: half the x fragment reads (timing only)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s + 1 < 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    if ((WIDE_EXP & 32) && (mt & 1)) bq[(s + 1) & 1][mt] = bq[(s + 1) & 1][mt - 1];
+                    else bq[(s + 1) & 1][mt] = bfrag(s + 1, mt);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == WIDE_W_ISSUE_STEP) {              // W loaders: between the halves of their MFMAs, when the x loaders are back to computing
+                if (!(WIDE_EXP & 4) && !xrole && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                if (WIDE_EXP & 1) asm volatile("" ::"v"(wf[s]), "v"(bq[s & 1][mt]));
+                else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], bq[s & 1][mt], acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#if WIDE_EXP & 16
+    if (EPI == EPI_PARTIAL && tid == 0) {
+        const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
+        uint32_t *dbg = reinterpret_cast<uint32_t *>(t.part + (int64_t)15 * M * t.Np) + (blockIdx.x + gridDim.x * blockIdx.y) * 2;
+        dbg[0] = (uint32_t)(st_c1 - st_c0), dbg[1] = (uint32_t)(st_r1 - st_r0);
+    }
+#endif
+    if (WIDE_EXP & 8) {
+        float tsum = 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int i = 0; i < 16; i++) t += acc[mt][i];
-        if (t == 12345.678f) part[0] = t;
+            for (int i = 0; i < 16; i++) tsum += acc[mt][i];
+        if (tsum == 12345.678f) t.part[0] = tsum;
         return;
     }
-    constexpr int kLd = kBN + 4;                       // floats per staged row: rows shift by 16 B -> conflict-free b128 writes
-    float *stage = reinterpret_cast<float *>(smem);    // the ring is no longer needed (MT*32 rows x 528 B <= its size)
-    __syncthreads();                                   // every compute wave is past its last fragment read
-    if (wave_live) {
-        // acc[mt][i]: m = mt*32 + (lane & 31), n = n0 + 8*(i>>2) + 4*h + (i&3)
+    // ---- epilogue: two passes of 128 columns through a row-major LDS staging area (the rings are no longer needed)
+    float *stg = reinterpret_cast<float *>(smem);
+    __syncthreads();                                   // every wave is past its last fragment read (no LDS-DMA is pending)
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
-            const int m = mt * 32 + r;
-            if (m >= M) continue;
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-                *reinterpret_cast<f32x4 *>(stage + m * kLd + wave * 32 + 8 * g + 4 * h) = o;
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const int c4 = tid & 31;                       // 4 columns per lane, 32 lanes per row, 8 rows per pass
-        const int n = n_base + 4 * c4;
-        if (n < Np) {
-            for (int m = tid >> 5; m < M; m += 8) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 4 * c4);
-                if (EPI == EPI_F16) {
-                    f16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float t = bias ? v[e] + (float)bias[n + e] : v[e];
-                        if (bs.relu_sq) {
-                            t = (float)(f16)t;               // relu(fp16(y))**2, rwkv7.py:678
-                            t = t > 0.f ? t * t : 0.f;
-                        }
-                        o[e] = (f16)t;
-                    }
-                    *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldyp + n) = o;
-                } else {
-                    *reinterpret_cast<f32x4 *>(part + ((int64_t)kslice * M + m) * Np + n) = v;
-                }
-            }
-        }
+    for (int half = 0; half < 2; half++) {
+        if ((wave >> 2) == half && wave_live) stage_acc<MT>(stg, acc, M, (wave & 3) * 32, r, h);
+        __syncthreads();
+        store_staged<EPI, 512>(stg, M, n_base + half * kTileRows, t, t.kslice, bs.relu_sq);
+        if (half == 0) __syncthreads();
     }
 }
-
 
 // Sum the split-K partials and apply the epilogue.
 //   mode 0: y = sum (+ bias[n]);  mode 1: y = relu(sum (+bias))^2;
@@ -583,47 +616,26 @@ __global__ __launch_bounds__(256) void mm8_prep_kernel(const int K, const f16 *_
     if (threadIdx.x < 3) S[m * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
-template <bool W8>
-int launch(int MT, bool partial, dim3 grid, size_t lds, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X,
-           int ldx, const void *W, int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part) {
-#define GO(MTV)                                                                                                              \
-    do {                                                                                                                     \
-        if (lds > 65536) {                                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>),                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_gemm_kernel<MTV, W8, EPI_F16>),                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                       \
-        }                                                                                                                    \
-        if (partial)                                                                                                         \
-            hipLaunchKernelGGL((skinny_gemm_kernel<MTV, W8, EPI_PARTIAL>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X, \
-                               ldx, W, ldw, Y, ldy, bias, part);                                                             \
-        else                                                                                                                 \
-            hipLaunchKernelGGL((skinny_gemm_kernel<MTV, W8, EPI_F16>), grid, dim3(kThreads), lds, st, M, N, K, k_slice, X,    \
-                               ldx, W, ldw, Y, ldy, bias, part);                                                             \
-    } while (0)
-    switch (MT) {
-        case 1: GO(1); break;
-        case 2: GO(2); break;
-        case 3: GO(3); break;
-        case 4: GO(4); break;
-        case 5: GO(5); break;
-        case 6: GO(6); break;
-        case 7: GO(7); break;
-        default: GO(8); break;
-    }
-#undef GO
-    return (int)hipGetLastError();
+// Output columns per workgroup.  256 wherever there are enough columns to fill the chip with 256-wide tiles at a sane
+// split (every big matrix of the model); 128 for the narrow problems.  CHIRRUP_GEMM_BN=128|256 forces one kernel (A/B).
+int choose_bn(int n_max) {
+    static const int forced = [] {
+        const char *e = getenv("CHIRRUP_GEMM_BN");
+        const int v = e ? atoi(e) : 0;
+        return (v == 128 || v == 256) ? v : 0;
+    }();
+    if (forced) return forced;
+    return n_max >= 32768 ? 256 : 128;
 }
 
-int g_mode = 3;             // 0: register-staged kernel; 1-3: LDS-DMA ring kernel variants (launch_ring_mode); 3 measured fastest
-
-int pick_splits(int N, int K, int requested, int Z = 1) {
+// K-split factor: enough workgroups for the 256 CUs, slices of whole, equal K-blocks, at least four per slice.
+int pick_splits(int bn, int N, int K, int requested, int Z = 1) {
     if (requested > 0) {                               // a request is honoured as far as K allows: whole, equal K-blocks
         int s = requested < K / kKB ? requested : K / kKB;
         while (s > 1 && (K / kKB) % s) s--;
         return s < 1 ? 1 : s;
     }
-    const int ngroups = Z * ((N + kBN - 1) / kBN);
+    const int ngroups = Z * ((N + bn - 1) / bn);
     int s = (256 + ngroups - 1) / ngroups;             // aim at >= 256 workgroups
     const int max_s = K / 256 > 0 ? K / 256 : 1;       // keep >= 4 K-blocks per slice
     if (s > max_s) s = max_s;
@@ -632,30 +644,38 @@ int pick_splits(int N, int K, int requested, int Z = 1) {
     return s;
 }
 
+size_t lds_bytes(int bn, int MT, bool w8) {
+    const size_t x = (size_t)MT * 32 * 128, stage = (size_t)MT * 32 * kLd * sizeof(float);
+    size_t ring;
+    if (bn == 256) ring = 2 * x + (size_t)(w8 ? 5 : WIDE_WD) * 2 * kTileRows * (w8 ? 64 : 128);
+    else ring = (size_t)(w8 ? 4 : 3) * (x + (size_t)kTileRows * (w8 ? 64 : 128));
+    return ring > stage ? ring : stage;
+}
+
 }  // namespace
 
-// MODE 1: one ring, every wave loads both operands; 2: x / W loader roles, x 2 slots / W 6 (u8: 8); 3: dedicated loader waves
-template <bool W8, int EPI, int MODE>
-int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                     int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs, const GroupTable &gt) {
-    constexpr int RM = MODE - 1;
-    constexpr int XD = MODE == 2 ? 2 : (W8 ? 4 : 3);
-    constexpr int WD = MODE == 2 ? (W8 ? 8 : 6) : XD;
-    const size_t ring = (size_t)XD * (MT * 32 * 128) + (size_t)WD * (kBN * (W8 ? 64 : 128));
-    const size_t stage = (size_t)MT * 32 * (kBN + 4) * sizeof(float);     // the epilogue's row-major staging area reuses the ring
-    const size_t lds = ring > stage ? ring : stage;
-#define GO(MTV)                                                                                                           \
+template <bool W8, int EPI>
+int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
+                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
+                const GroupTable &gt = GroupTable{}) {
+    const size_t lds = lds_bytes(bn, MT, W8);
+#define GO_K(KERN, MTV)                                                                                                   \
     do {                                                                                                                  \
-        auto kern = skinny_gemm_ring_kernel<MTV, W8, EPI, XD, WD, RM>;                                                    \
-        static bool lds_limit_raised[32] = {};     /* per instantiation AND device (one engine process drives several */  \
-        int dev_ = 0;                              /* GPUs); the call is idempotent, a race is harmless */                 \
+        auto kern = KERN<MTV, W8, EPI>;                                                                                   \
+        static std::atomic<bool> lds_limit_raised[32];   /* per instantiation AND device (one engine process may drive */ \
+        int dev_ = 0;                                    /* several GPUs); the call itself is idempotent */               \
         (void)hipGetDevice(&dev_);                                                                                        \
-        if (!lds_limit_raised[dev_ & 31]) {                                                                               \
+        if (!lds_limit_raised[dev_ & 31].load(std::memory_order_acquire)) {                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                       (int)lds);                                                                          \
-            lds_limit_raised[dev_ & 31] = true;                                                                           \
+            lds_limit_raised[dev_ & 31].store(true, std::memory_order_release);                                           \
         }                                                                                                                 \
-        hipLaunchKernelGGL(kern, grid, dim3(RM == 2 ? 512 : kThreads), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
+    } while (0)
+#define GO(MTV)                                       \
+    do {                                              \
+        if (bn == 256) GO_K(wide_gemm_kernel, MTV);   \
+        else GO_K(ring_gemm_kernel, MTV);             \
     } while (0)
     switch (MT) {
         case 1: GO(1); break;
@@ -668,23 +688,13 @@ int launch_ring_mode(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int
         default: GO(8); break;
     }
 #undef GO
+#undef GO_K
     return (int)hipGetLastError();
 }
 
-template <bool W8, int EPI>
-int launch_ring(int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
-                int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
-                const GroupTable &gt = GroupTable{}) {
-    switch (g_mode) {
-        case 2: return launch_ring_mode<W8, EPI, 2>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
-        case 3: return launch_ring_mode<W8, EPI, 3>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
-        default: return launch_ring_mode<W8, EPI, 1>(MT, grid, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt);
-    }
-}
-
 namespace {
-// W [N][K] row-major -> tile images: tile (N-group g, K-block b) = 1024 chunks of 16 B in the order the ring kernel
-// keeps them in LDS (row nr = c >> 3 at chunk position c & 7 holds logical chunk (c & 7) ^ ((nr >> 1) & 7)).
+// W [N][K] row-major -> tile images: tile (N-group g, K-block b) = 1024 chunks of 16 B in the order the kernels
+// keep them in LDS (row nr = c >> 3 at chunk position c & 7 holds logical chunk (c & 7) ^ ((nr >> 1) & 7)).
 __global__ __launch_bounds__(256) void tile_weight_kernel(const int N, const int K, const f16 *__restrict__ W, const int64_t ldw,
                                                           f16 *__restrict__ Wt) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(256) void tile_weight_kernel(const int N, const int
     const int64_t tile = c >> 10;
     const int kb = (int)(tile % (K / kKB)), ng = (int)(tile / (K / kKB));
     const int nr = g >> 3, lc = (g & 7) ^ ((nr >> 1) & 7);
-    *reinterpret_cast<f16x8 *>(Wt + c * 8) = *reinterpret_cast<const f16x8 *>(W + ((int64_t)ng * kBN + nr) * ldw + kb * kKB + lc * 8);
+    *reinterpret_cast<f16x8 *>(Wt + c * 8) = *reinterpret_cast<const f16x8 *>(W + ((int64_t)ng * kTileRows + nr) * ldw + kb * kKB + lc * 8);
 }
 // uint8 form: tile (g, b) = 512 chunks of 16 B; row nr = c >> 2 at chunk position c & 3 holds logical chunk (c & 3) ^ ((nr >> 2) & 3)
 __global__ __launch_bounds__(256) void tile_weight_u8_kernel(const int N, const int K, const uint8_t *__restrict__ W, const int64_t ldw,
@@ -706,36 +716,44 @@ __global__ __launch_bounds__(256) void tile_weight_u8_kernel(const int N, const 
     const int64_t tile = c >> 9;
     const int kb = (int)(tile % (K / kKB)), ng = (int)(tile / (K / kKB));
     const int nr = g >> 2, lc = (g & 3) ^ ((nr >> 2) & 3);
-    *reinterpret_cast<u32x4 *>(Wt + c * 16) = *reinterpret_cast<const u32x4 *>(W + ((int64_t)ng * kBN + nr) * ldw + kb * kKB + lc * 16);
+    *reinterpret_cast<u32x4 *>(Wt + c * 16) = *reinterpret_cast<const u32x4 *>(W + ((int64_t)ng * kTileRows + nr) * ldw + kb * kKB + lc * 16);
 }
+
+inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 }  // namespace
 
 // The same for the uint8 (mm8) weights wT [M_out][N_in] of mm8t_seq (w_tiled = 1 there): 8-KiB tile images.
 extern "C" int skinny_tile_weight_u8(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream) {
-    if (N <= 0 || K <= 0 || (N % kBN) || (K % kKB) || ldw < K || (ldw & 15)) return CHIRRUP_E_SHAPE;
+    if (N <= 0 || K <= 0 || (N % kTileRows) || (K % kKB) || ldw < K || (ldw & 15)) return CHIRRUP_E_SHAPE;
     if (!W || !Wt) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Wt) & 15)) return CHIRRUP_E_ALIGN;
+    if (mis16(W) || mis16(Wt)) return CHIRRUP_E_ALIGN;
     const int64_t total = (int64_t)N * K / 16;
     hipLaunchKernelGGL(tile_weight_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        N, K, static_cast<const uint8_t *>(W), ldw, static_cast<uint8_t *>(Wt));
     return (int)hipGetLastError();
 }
 
-// Re-lay a binary16 weight matrix W [N][K] (N % 128 == 0, K % 64 == 0) as contiguous 16-KiB tile images for the ring
-// kernel (w_tiled = 1 in the GEMM calls).  Wt needs N*K elements; W and Wt must not overlap.
+// Re-lay a binary16 weight matrix W [N][K] (N % 128 == 0, K % 64 == 0) as contiguous 16-KiB tile images for the GEMM
+// kernels (w_tiled = 1 in the GEMM calls).  Wt needs N*K elements; W and Wt must not overlap.
 extern "C" int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream) {
-    if (N <= 0 || K <= 0 || (N % kBN) || (K % kKB) || ldw < K || (ldw & 7)) return CHIRRUP_E_SHAPE;
+    if (N <= 0 || K <= 0 || (N % kTileRows) || (K % kKB) || ldw < K || (ldw & 7)) return CHIRRUP_E_SHAPE;
     if (!W || !Wt) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Wt) & 15)) return CHIRRUP_E_ALIGN;
+    if (mis16(W) || mis16(Wt)) return CHIRRUP_E_ALIGN;
     const int64_t total = (int64_t)N * K / 8;
     hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        N, K, static_cast<const f16 *>(W), ldw, static_cast<f16 *>(Wt));
     return (int)hipGetLastError();
 }
 
+// The split count a call with these arguments uses (splits = 0: the library's choice) -- for sizing partial buffers.
+extern "C" int skinny_gemm_splits(int N, int K, int Z, int splits) {
+    if (N <= 0 || K <= 0 || Z <= 0 || (K % kKB)) return 0;
+    return pick_splits(choose_bn(N), N, K, splits, Z);
+}
+
 extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int s = pick_splits(N, K, splits);
+    const int s = pick_splits(choose_bn(N), N, K, splits);
     return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
 }
 
@@ -744,30 +762,24 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
                                const void *bias, void *Y, int ldy, int act, int splits, void *workspace, void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N || (ldx & 7) || (ldw & 7) || (ldy & 3))
         return CHIRRUP_E_SHAPE;
-    if (w_tiled && ((N % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
+    if (act < 0 || act > 1) return CHIRRUP_E_UNSUPPORTED;
+    if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
-        return CHIRRUP_E_ALIGN;
-    const int s = pick_splits(N, K, splits);
-    const bool partial = s > 1 || (act != 0 && !(g_mode && act == 1));     // unsplit relu^2 runs in the ring kernel's epilogue
+    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7)) return CHIRRUP_E_ALIGN;
+    const int bn = choose_bn(N);
+    const int s = pick_splits(bn, N, K, splits);
+    const bool partial = s > 1;                        // unsplit: bias and relu^2 run in the kernel's own epilogue
     if (partial && !workspace) return CHIRRUP_E_NULL;
     const int MT = (M + 31) / 32;
-    const int k_slice = K / s;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((N + kBN - 1) / kBN, s);
-    const size_t lds = (size_t)2 * MT * 32 * 128;
-    int rc;
+    const dim3 grid((N + bn - 1) / bn, s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
     bs.relu_sq = (!partial && act == 1) ? 1 : 0;
-    if (g_mode)
-        rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y,
-                                                       ldy, (const f16 *)bias, (float *)workspace, bs)
-                     : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+    int rc = partial ? launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                                                       (const f16 *)bias, (float *)workspace, bs)
+                     : launch_gemm<false, EPI_F16>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                    (const f16 *)bias, (float *)workspace, bs);
-    else
-        rc = launch<false>(MT, partial, grid, lds, st, M, N, K, k_slice, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
-                           (const f16 *)bias, (float *)workspace);
     if (rc) return rc;
     if (partial) {
         const int64_t total = (int64_t)M * N / 4;
@@ -780,7 +792,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
 
 extern "C" int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int K, int splits) {
     if (Z <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
-    return (int64_t)Z * pick_splits(N, K, splits, Z) * M * N * (int64_t)sizeof(float);
+    return (int64_t)Z * pick_splits(choose_bn(N), N, K, splits, Z) * M * N * (int64_t)sizeof(float);
 }
 
 // Z independent problems in ONE launch: Y[z] = act(X[z] . W[z]^T + bias[z]); operands of problem z start z * (their
@@ -803,15 +815,14 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
         (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
         return CHIRRUP_E_SHAPE;
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(Y) & 7))
-        return CHIRRUP_E_ALIGN;
-    if (!g_mode) return CHIRRUP_E_UNSUPPORTED;            // the register-staged variant has no batch dimension
-    const int s = pick_splits(N, K, splits, Z);
+    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7)) return CHIRRUP_E_ALIGN;
+    const int bn = choose_bn(N);
+    const int s = pick_splits(bn, N, K, splits, Z);
     const bool partial = s > 1 || act != 0;
     if (partial && !workspace) return CHIRRUP_E_NULL;
     const int MT = (M + 31) / 32;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((N + kBN - 1) / kBN, s, Z);
+    const dim3 grid((N + bn - 1) / bn, s, Z);
     BatchStrides bs{};
     bs.x = x_bs, bs.w = w_bs, bs.y = y_bs, bs.bias = bias_bs;
     if (k_of) {
@@ -821,9 +832,9 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
             bs.k[z] = k_of[z];
         }
     }
-    int rc = partial ? launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+    int rc = partial ? launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                        (const f16 *)bias, (float *)workspace, bs)
-                     : launch_ring<false, EPI_F16>(MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
+                     : launch_gemm<false, EPI_F16>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                    (const f16 *)bias, (float *)workspace, bs);
     if (rc) return rc;
     if (partial) {
@@ -836,24 +847,46 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
     return rc;
 }
 
-extern "C" int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int splits) {
-    if (count <= 0 || count > 8 || !problems || M <= 0 || splits <= 0) return 0;
+namespace {
+int group_bn_and_splits(int count, const chirrup_gemm_problem *problems, int K, int splits, int &s_out) {
+    int max_n = 0, sum_groups = 0;
+    for (int i = 0; i < count; i++) max_n = problems[i].n > max_n ? problems[i].n : max_n;
+    const int bn = choose_bn(max_n);
+    for (int i = 0; i < count; i++) sum_groups += (problems[i].n + bn - 1) / bn;
+    if (splits > 0) {
+        s_out = splits;
+    } else {                                           // as pick_splits, over the launch's exact tile list
+        int s = (256 + sum_groups - 1) / sum_groups;
+        const int max_s = K / 256 > 0 ? K / 256 : 1;
+        s = s > max_s ? max_s : (s < 1 ? 1 : s);
+        while (s > 1 && (K / kKB) % s) s--;
+        s_out = s;
+    }
+    return bn;
+}
+}  // namespace
+
+extern "C" int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int K, int splits) {
+    if (count <= 0 || count > 8 || !problems || M <= 0 || K <= 0 || (K % kKB) || splits < 0) return 0;
+    int s;
+    group_bn_and_splits(count, problems, K, splits, s);
     int64_t b = 0;
-    for (int i = 0; i < count; i++) b += ((int64_t)splits * M * problems[i].n * (int64_t)sizeof(float) + 255) / 256 * 256;
+    for (int i = 0; i < count; i++) b += ((int64_t)s * M * problems[i].n * (int64_t)sizeof(float) + 255) / 256 * 256;
     return b;
 }
 
 // Up to 8 GEMMs that share M, K, the row strides of x and W and the split count, in ONE launch (+ one reduce launch):
 // y_i = act_i(x_i . w_i^T + bias_i).  Always goes through split-K partials (splits >= 1) so that the activations run in
-// the reduce kernel; workgroups are dealt over the largest problem's N-groups, the smaller problems' spare ones exit.
+// the reduce kernel; blockIdx.x runs over the exact list of the problems' N-groups.
 extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw,
                                      int splits, void *workspace, void *stream) {
     if (count <= 0 || count > 8 || !problems) return CHIRRUP_E_SHAPE;
-    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || splits <= 0 ||
-        ((K / kKB) % splits))
+    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || splits < 0 ||
+        (splits > 0 && ((K / kKB) % splits)))
         return CHIRRUP_E_SHAPE;
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return workspace ? CHIRRUP_E_ALIGN : CHIRRUP_E_NULL;
-    if (!g_mode) return CHIRRUP_E_UNSUPPORTED;
+    int s;
+    const int bn = group_bn_and_splits(count, problems, K, splits, s);
     GroupTable gt{};
     gt.used = count;
     int max_n = 0;
@@ -862,25 +895,24 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
         const chirrup_gemm_problem &q = problems[i];
         if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
         if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
-        if ((reinterpret_cast<uintptr_t>(q.x) & 15) || (reinterpret_cast<uintptr_t>(q.w) & 15) || (reinterpret_cast<uintptr_t>(q.y) & 7))
-            return CHIRRUP_E_ALIGN;
+        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7)) return CHIRRUP_E_ALIGN;
         gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y);
         gt.bias[i] = static_cast<const f16 *>(q.bias), gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act;
-        if (q.w_tiled && (q.n % kBN)) return CHIRRUP_E_UNSUPPORTED;
+        if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
         gt.tiled[i] = q.w_tiled ? 1 : 0;
         gt.part[i] = reinterpret_cast<float *>(ws);
-        ws += ((int64_t)splits * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
+        ws += ((int64_t)s * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
         max_n = q.n > max_n ? q.n : max_n;
-        gt.first[i + 1] = gt.first[i] + (q.n + kBN - 1) / kBN;
+        gt.first[i + 1] = gt.first[i] + (q.n + bn - 1) / bn;
     }
     const int MT = (M + 31) / 32;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(gt.first[count], splits, 1);
-    int rc = launch_ring<false, EPI_PARTIAL>(MT, grid, st, M, max_n, K, K / splits, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
+    const dim3 grid(gt.first[count], s, 1);
+    int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
                                              nullptr, gt.part[0], BatchStrides{}, gt);
     if (rc) return rc;
     const int64_t total = (int64_t)M * max_n / 4;
-    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, M, max_n, splits,
+    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, M, max_n, s,
                        (const float *)nullptr, (const f16 *)nullptr, nullptr, nullptr, nullptr, 0, (f16 *)nullptr, 0, (int64_t)0,
                        (int64_t)0, gt);
     return (int)hipGetLastError();
@@ -891,15 +923,15 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7))
         return CHIRRUP_E_SHAPE;
     if (!X || !W || !partials) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(partials) & 15))
-        return CHIRRUP_E_ALIGN;
-    const int s = pick_splits(N, K, splits);
+    if (mis16(X) || mis16(W) || mis16(partials)) return CHIRRUP_E_ALIGN;
+    if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    const int bn = choose_bn(N);
+    const int s = pick_splits(bn, N, K, splits);
     const int MT = (M + 31) / 32;
-    const dim3 grid((N + kBN - 1) / kBN, s);
-    if (w_tiled && ((N % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
+    const dim3 grid((N + bn - 1) / bn, s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    const int rc = launch_ring<false, EPI_PARTIAL>(MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
+    const int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
                                                    W, ldw, nullptr, N, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
 }
@@ -910,7 +942,7 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
 extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) {
     if (B <= 0 || N_in <= 0 || M_out <= 0) return 0;
     if (B > 256) B = 256;                                  // more rows are processed 256 at a time
-    const int s = pick_splits(M_out, N_in, splits);
+    const int s = pick_splits(choose_bn(M_out), M_out, N_in, splits);
     int64_t b = (int64_t)B * N_in * 2;
     b = (b + 255) / 256 * 256;
     b += 256 * ((B * 3 * 4 + 255) / 256);
@@ -921,15 +953,15 @@ extern "C" int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits) 
 extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
                         const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
                         int splits, void *workspace, void *stream) {
-    if (w_tiled && ((M_out % kBN) || !g_mode)) return CHIRRUP_E_UNSUPPORTED;
+    if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     if (B <= 0 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
         y_stride < M_out || (x_stride & 7) || (w_stride & 15) || (y_stride & 3))
         return CHIRRUP_E_SHAPE;
     if (!x || !wT || !mx || !rx || !my || !ry || !y || !workspace) return CHIRRUP_E_NULL;
-    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(wT) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 255))
-        return CHIRRUP_E_ALIGN;
+    if (mis16(x) || mis16(wT) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return CHIRRUP_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int s = pick_splits(M_out, N_in, splits);
+    const int bnc = choose_bn(M_out);
+    const int s = pick_splits(bnc, M_out, N_in, splits);
     const int Bmax = B < 256 ? B : 256;
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     f16 *xs = reinterpret_cast<f16 *>(ws);
@@ -937,7 +969,7 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
     float *S = reinterpret_cast<float *>(ws + off);
     off += 256 * ((Bmax * 3 * 4 + 255) / 256);
     float *part = reinterpret_cast<float *>(ws + off);
-    // The kernel holds at most 256 activation rows per weight pass (8 accumulator tiles per wave): a longer batch
+    // The kernels hold at most 256 activation rows per weight pass (8 accumulator tiles per wave): a longer batch
     // (chunked prefill) is cut into 256-row blocks that re-stream the weights; the blocks reuse the workspace in
     // stream order.
     for (int b0 = 0; b0 < B; b0 += 256) {
@@ -947,14 +979,11 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         hipLaunchKernelGGL(mm8_prep_kernel, dim3(bn), dim3(256), 0, st, N_in, xb, x_stride, (const f16 *)ry, (const f16 *)my,
                            xs, S);
         const int MT = (bn + 31) / 32;
-        const dim3 grid((M_out + kBN - 1) / kBN, s);
-        const size_t lds = (size_t)2 * MT * 32 * 128;
+        const dim3 grid((M_out + bnc - 1) / bnc, s);
         BatchStrides bs{};
         bs.tiled = w_tiled ? 1 : 0;
-        int rc = g_mode ? launch_ring<true, EPI_PARTIAL>(MT, grid, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb,
-                                                         y_stride, nullptr, part, bs)
-                        : launch<true>(MT, true, grid, lds, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb, y_stride,
-                                       nullptr, part);
+        int rc = launch_gemm<true, EPI_PARTIAL>(bnc, MT, grid, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb, y_stride,
+                                                nullptr, part, bs);
         if (rc) return rc;
         const int64_t total = (int64_t)bn * M_out / 4;
         hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bn, M_out, s, part,
@@ -964,5 +993,3 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
     }
     return 0;
 }
-
-extern "C" void skinny_gemm_select(int mode) { g_mode = mode < 0 || mode > 3 ? 3 : mode; }

@@ -45,10 +45,10 @@ SIGNATURES = {
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
-    "skinny_gemm_select": (None, [_i]),
+    "skinny_gemm_splits": (_i, [_i, _i, _i, _i]),
     "skinny_gemm_batched_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "skinny_gemm_f16_batched": (_i, [_i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i64, _i, _i, _vp, _vp]),
-    "skinny_gemm_group_workspace_bytes": (_i64, [_i, _vp, _i, _i]),
+    "skinny_gemm_group_workspace_bytes": (_i64, [_i, _vp, _i, _i, _i]),
     "skinny_gemm_f16_group": (_i, [_i, _vp, _i, _i, _i, _i64, _i, _vp, _vp]),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),

@@ -428,10 +428,16 @@ class _GemmProblem(ctypes.Structure):
 _GROUP_ACTS = {None: 0, "relu_sq": 1, "tanh": 2, "sigmoid": 3}
 
 
-def skinny_group(problems, splits: int = 2):
+def gemm_splits(N: int, K: int, Z: int = 1, splits: int = 0) -> int:
+    """The K-split factor the library uses for an [.., K] x [N, K]^T product (splits = 0: its own choice)."""
+    return _lib.load().skinny_gemm_splits(N, K, Z, splits)
+
+
+def skinny_group(problems, splits: int = 0):
     """Several GEMMs over the same rows in ONE launch (+ one reduce): ``problems`` is a list of
     (x [M,K], weight [N,K], out [M,N], bias [N] or None, act in {None, "relu_sq", "tanh", "sigmoid"}); all x share
-    M <= 256, K (% 64 * splits == 0) and their row stride, all weights share their row stride.  Writes the outs."""
+    M <= 256, K (% 64 * splits == 0) and their row stride, all weights share their row stride.  Writes the outs.
+    splits = 0: the library's choice."""
     if not 0 < len(problems) <= 8:
         raise _lib.ChirrupAmdError("skinny_group: 1..8 problems")
     x0 = problems[0][0]
@@ -453,7 +459,7 @@ def skinny_group(problems, splits: int = 2):
             _chk16("bias", bias, N)
         arr[i] = _GemmProblem(x.data_ptr(), wptr, out.data_ptr(), _ptr(bias) or None, N, out.stride(0), _GROUP_ACTS[act], w_tiled)
     L = _lib.load()
-    nbytes = L.skinny_gemm_group_workspace_bytes(len(problems), ctypes.addressof(arr), M, splits)
+    nbytes = L.skinny_gemm_group_workspace_bytes(len(problems), ctypes.addressof(arr), M, K, splits)
     ws = _workspace(nbytes + 256, x0.device)
     base = (ws.data_ptr() + 255) // 256 * 256
     rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), ldw0 if ldw0 is not None else K, splits,

@@ -207,6 +207,8 @@ class RWKV_x070:
         self._head_t = None
         self.skinny_att_out = True                       # att.output through the ring kernel, its reduce folded into LN2
         self.skinny_ffn_key = True                       # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
+        # K-split factors of the hand-written GEMMs (0 = the library's choice); tuning knobs for tools/ and bench.py
+        self.gemm_splits = {"rkv": 0, "att_out": 0, "ffn_key": 0, "ffn_value": 0}
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -414,8 +416,10 @@ class RWKV_x070:
         # FFN matrices on top of that (`use_parts`; the mm8 FFN has its own kernels)
         hw = self.skinny_ffn_value and self.skinny_min_rows <= rows <= 256 and C >= self.skinny_min_embd
         use_parts = hw and self.ffn_dtype == torch.float16
-        pbuf = torch.empty((8, rows, C), dtype=torch.float32, device=dev) if use_parts else None
-        pbuf_o = (torch.empty((4, rows, C), dtype=torch.float32, device=dev)
+        gs = self.gemm_splits
+        pbuf = (torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), dtype=torch.float32, device=dev)
+                if use_parts else None)
+        pbuf_o = (torch.empty((ops.gemm_splits(C, C, 1, gs["att_out"]), rows, C), dtype=torch.float32, device=dev)
                   if (hw and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
 
         def commit_carry(prev):
@@ -452,7 +456,7 @@ class RWKV_x070:
                 for j in range(p0, 4):
                     kj = lw.lora_k[j]
                     probs.append((mixed[2 + j], lw.lora1[j, :kj], hid[j - p0, :, :kj], None, ("tanh" if j == 1 else ("sigmoid" if j == 3 else None))))
-                ops.skinny_group(probs, splits=2)
+                ops.skinny_group(probs, splits=gs["rkv"])
                 up = ops.skinny_bmm(hid[: 4 - p0], lw.lora2[p0:], lw.lbias[p0:], splits=1, k_of=lw.lora_k[p0:])
                 side = None
             if side is not None:
@@ -495,7 +499,7 @@ class RWKV_x070:
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
             if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
-                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, 4, pbuf_o)   # split 4: half the partial traffic of 8 (7.77 -> 7.72 ms); reduce folded into the LN below
+                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, gs["att_out"], pbuf_o)   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
                                prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
             else:
@@ -510,7 +514,7 @@ class RWKV_x070:
                 delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)
             else:
                 if use_parts and self.skinny_ffn_key and rows >= self.skinny_wide_rows:
-                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=2)     # unsplit (128 workgroups, relu^2 in the epilogue, no reduce) is slower: 7.70 vs 7.26 ms
+                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=gs["ffn_key"])
                 else:
                     kf = F.linear(kin[0], lw.f_K)
                     ops.relu_sq_(kf)
@@ -520,7 +524,7 @@ class RWKV_x070:
                     # K = 4C >> N = C at decode batch sizes: the hand-written LDS-DMA ring GEMM streams this
                     # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200);
                     # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
-                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), 8, pbuf), None
+                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), gs["ffn_value"], pbuf), None
                 else:
                     delta = kf @ lw.f_V
         if dparts is not None and (T > 1 and not full_output):

@@ -174,10 +174,12 @@ int rwkv7_relu_sq(int64_t n, void *x, void *stream);
  * :551) for batch sizes where the library GEMM is operand-ingest bound.
  * W row-major [N][K] (the layout the reference keeps its `*.weight` tensors in), row stride ldw
  * elements; K % 64 == 0, N % 4 == 0, ldx % 8 == 0, ldw % 8 == 0.  act: 0 none, 1 relu(.)^2 (rwkv7.py:678).
- * splits: K-split factor (0 = choose); needs skinny_gemm_workspace_bytes(M,N,K,splits) bytes of
- * device scratch when that is > 0 or act != 0.
+ * splits: K-split factor (0 = the library's choice: enough workgroups for the 256 CUs at the kernel's tile width);
+ * needs skinny_gemm_workspace_bytes(M,N,K,splits) bytes of device scratch when that is > 0.
+ * skinny_gemm_splits: the factor a call with these sizes uses (Z = problems of a batched launch, 1 otherwise).
  */
 int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits);
+int skinny_gemm_splits(int N, int K, int Z, int splits);
 /* As skinny_gemm_f16 without bias/activation, but leaves the `splits` binary32 partial results
  * [splits][M][N] in `partials` for the consumer to sum (see rwkv7_add_ln_mix). Returns the split count used
  * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
@@ -203,7 +205,7 @@ int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const v
  * key / value projections together with its four LoRA down-projections and their activations (Albatross/rwkv7.py:
  * 625-637): seven independent GEMMs over the same token rows that the reference issues one by one.
  * act: 0 none, 1 relu(.)^2, 2 tanh, 3 sigmoid (applied to the binary16-rounded sum, like a separate torch op).
- * workspace: skinny_gemm_group_workspace_bytes(...) bytes, 256-byte aligned. */
+ * splits = 0: the library's choice.  workspace: skinny_gemm_group_workspace_bytes(...) bytes, 256-byte aligned. */
 typedef struct {
     const void *x;     /* [M][ldx] binary16 */
     const void *w;     /* [n][ldw] binary16 */
@@ -212,12 +214,9 @@ typedef struct {
     int n, ldy, act;
     int w_tiled;       /* w is in the tile-image layout (skinny_tile_weight); needs n % 128 == 0 */
 } chirrup_gemm_problem;
-int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int splits);
+int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int K, int splits);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
                           void *workspace, void *stream);
-/* Kernel variant (A/B switch): 0 register-staged; 1 both operands through one LDS-DMA ring loaded by the compute
- * waves; 2 per-wave x / W loader roles; 3 (default) four dedicated loader waves (see skinny_gemm.hip). */
-void skinny_gemm_select(int mode);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
                     void *Y, int ldy, int act, int splits, void *workspace, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
