@@ -10,9 +10,16 @@ Weights, states and inputs are resident in HBM before the timed region.  Multi-G
 reference's only parallelism: independent replicas, one process per GPU, a
 batch of B per GPU, no data-path collective ("scaling": "weak").
 
+The sampling half of a step is what Worker._run_forward_one does for greedy rows (chirrup/worker.py:719-740): the fused
+penalties + arg-max kernel over per-slot occurrence / presence tables (zero penalties, decay 1: the same bytes move),
+then the device-side commit of the sampled ids (next input, occurrence += 1, presence) and the asynchronous id copy.
+
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     -- the WKV7 kernel: algorithmic bytes B*(270*C+4) per launch / HIP-event launch time
-  cpu_baseline -- the CPU oracle (port of the reference arithmetic) on a bounded sample
+  roofline      -- the WKV7 kernel: algorithmic bytes B*(270*C+4) per launch / HIP-event launch time
+  gemm_roofline -- one entry per GEMM launch of a layer (+ head): ALGORITHMIC bytes (weight + x + y; split-K partials are
+                   not algorithmic) / HIP-event time of the model's own call, PMC traffic where profiles/ holds it
+  mm8           -- the same step with uint8 (w8a16) FFN weights: ms/step, the two u8 GEMMs against N*M + 4(N+M) + 2B(N+M)
+  cpu_baseline  -- the CPU oracle (port of the reference arithmetic) on a bounded sample
 """
 import argparse
 import json
@@ -41,6 +48,8 @@ def parse():
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-mm8-leg", action="store_true", help="skip the second (uint8 FFN) model of the mm8 object")
+    p.add_argument("--no-penalties", action="store_true", help="plain arg-max instead of the worker's penalty tables + commit (round 1's step)")
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
@@ -128,27 +137,8 @@ def wkv7_event_timing(model, state, B, iters=6, fused=True):
     return ms[len(ms) // 2]
 
 
-def gemm_event_timing(model, B, iters=6):
-    """Average duration (ms) of the ring-GEMM launch that dominates the step by time, at the ffn.value shape
-    ([B, 4C] x [4C, C]^T, split 8, fp32 partials): HIP-graph replay of L back-to-back launches, one per layer's own
-    weight (L x 134 MB in rotation at 7.2B >> the 256 MiB Infinity Cache).  None when the model does not use the
-    hand-written path (mm8 FFN)."""
-    from chirrup_amd import ops
-
-    C, L = model.n_embd, model.n_layer
-    dev = model.device
-    if any(lw.f_V is None for lw in model._layers) or B > 256:
-        return None
-    g = torch.Generator(device=dev)
-    g.manual_seed(6)
-    x = torch.randn((B, 4 * C), generator=g, device=dev).half()
-    pbuf = torch.empty((8, B, C), dtype=torch.float32, device=dev)
-    ws = [lw.f_V_t if lw.f_V_t is not None else lw.f_V.t() for lw in model._layers]
-
-    def run():
-        for w in ws:
-            ops.skinny_linear_partial(x, w, 8, pbuf)
-
+def _replay_time(run, n_per_replay, iters=6):
+    """Median time (ms) of one of the n_per_replay calls that `run` makes, from HIP events around graph replays."""
     run()
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
@@ -161,9 +151,100 @@ def gemm_event_timing(model, B, iters=6):
         graph.replay()
         e1.record()
         torch.cuda.synchronize()
-        ms.append(e0.elapsed_time(e1) / L)
+        ms.append(e0.elapsed_time(e1) / n_per_replay)
     ms = sorted(ms[1:])
     return ms[len(ms) // 2]
+
+
+def gemm_shape_timings(model, B):
+    """Every GEMM launch of a decode layer (and the head), timed as the model calls it: HIP-graph replay of L back-to-back
+    calls, one per layer's own weights (L x 33..134 MB in rotation >> the 256 MiB Infinity Cache).  Returns
+    {shape: (ms, algorithmic bytes, what the call contains)}; {} when the model does not use the hand-written path."""
+    from chirrup_amd import ops
+
+    C, L, V = model.n_embd, model.n_layer, 65536
+    dev = model.device
+    lws = model._layers
+    if B > 256 or lws[0].rkv_t is None:
+        return {}
+    g = torch.Generator(device=dev)
+    g.manual_seed(6)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=dev).half()
+    gs = model.gemm_splits
+    out = {}
+    mixed, rkv = rnd(6, B, C), torch.empty((3, B, C), dtype=torch.float16, device=dev)
+    dmax = lws[0].lora1.shape[1]
+    hid = torch.zeros((4, B, dmax), dtype=torch.float16, device=dev)
+    ranks = lws[1].lora_k
+
+    def rkv_lora():
+        for lw in lws:
+            probs = [(mixed[j], lw.rkv_t[j], rkv[j], None, None) for j in range(3)]
+            probs += [(mixed[2 + j], lw.lora1[j, :ranks[j]], hid[j, :, :ranks[j]], None, "tanh" if j == 1 else ("sigmoid" if j == 3 else None))
+                      for j in range(4)]
+            ops.skinny_group(probs, splits=gs["rkv"])
+
+    n_dn = sum(ranks)
+    out["rkv_lora_down"] = (_replay_time(rkv_lora, L), (3 * C + n_dn) * C * 2 + 6 * B * C * 2 + B * (3 * C + n_dn) * 2,
+                            "grouped launch of R/K/V + 4 LoRA down-projections + its reduce (tanh / sigmoid)")
+
+    def lora_up():
+        for lw in lws:
+            ops.skinny_bmm(hid, lw.lora2, lw.lbias, splits=1, k_of=ranks)
+
+    out["lora_up"] = (_replay_time(lora_up, L), n_dn * C * 2 + B * n_dn * 2 + 4 * B * C * 2, "batched launch of the 4 LoRA up-projections, bias in the epilogue")
+    x_c, x_4c = rnd(B, C), rnd(B, 4 * C)
+    pbuf = torch.empty((16, B, C), dtype=torch.float32, device=dev)
+
+    def att_out():
+        for lw in lws:
+            ops.skinny_linear_partial(x_c, lw.O_t, gs["att_out"], pbuf)
+
+    out["att_output"] = (_replay_time(att_out, L), C * C * 2 + 2 * B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
+    if lws[0].f_K_t is not None:
+        def ffn_key():
+            for lw in lws:
+                ops.skinny_linear(x_c, lw.f_K_t, act=1, splits=gs["ffn_key"])
+
+        def ffn_value():
+            for lw in lws:
+                ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf)
+
+        out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "GEMM kernel + reduce with relu^2")
+        out["ffn_value"] = (_replay_time(ffn_value, L), 4 * C * C * 2 + B * 4 * C * 2 + B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
+    elif lws[0].f_K8 is not None:
+        def ffn_key8():
+            for lw in lws:
+                ops.mm8t_linear(x_c, *lw.f_K8, act=1, tiled=lw.f8_tiled)
+
+        def ffn_value8():
+            for lw in lws:
+                ops.mm8t_linear(x_4c, *lw.f_V8, tiled=lw.f8_tiled)
+
+        mm8_bytes = lambda n, m: n * m + 4 * (n + m) + 2 * B * (n + m)             # SURVEY 8d
+        out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C), "mm8: activation prologue + u8 GEMM kernel + reduce (rank-1 corrections, relu^2)")
+        out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "mm8: activation prologue + u8 GEMM kernel + reduce (rank-1 corrections)")
+    if model._head_t is not None:
+        out["head"] = (_replay_time(lambda: ops.skinny_linear(x_c, model._head_t, splits=1), 1), V * C * 2 + B * C * 2 + B * V * 2,
+                       "unsplit GEMM kernel, fp16 epilogue")
+    return out
+
+
+def gemm_roofline_object(timings, L):
+    traffic = {}
+    f = os.path.join(ROOT, "profiles", "r02_gemm_pmc_traffic.json")
+    if os.path.exists(f):
+        for shape, rec in json.load(open(f))["shapes"].items():
+            traffic[shape.replace(".", "_")] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+    shapes = {}
+    for name, (ms, nbytes, what) in timings.items():
+        ach = nbytes / (ms * 1e-3) / 1e9
+        shapes[name] = {"launch_us": round(ms * 1e3, 2), "algorithmic_bytes": nbytes, "achieved": round(ach, 1),
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name), "what": what,
+                        "launches_per_step": 1 if name == "head" else L}
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bytes": "algorithmic: weight + x + y (fp16); split-K partials are not counted; traffic = HBM read + written bytes incl. partials (profiles/r02_gemm_pmc_traffic.json)",
+            "shapes": shapes}
 
 
 def recorded_traffic(B, C, fused=False):
@@ -173,7 +254,7 @@ def recorded_traffic(B, C, fused=False):
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
         rec = json.load(open(f))
-        if ("<1>" in rec["kernel"]) != fused:
+        if "kernel" not in rec or ("<1>" in rec["kernel"]) != fused:
             continue
         if rec["shape"]["B"] == B and rec["shape"]["C"] == C:
             return rec["traffic_bytes_per_launch"], os.path.basename(f)
@@ -231,6 +312,78 @@ def cpu_baseline(name, B, n_layers):
                       f"{t_all:.1f}s measured, scaled to {L} layers"}
 
 
+def timed_decode(model, B, a, dev, rank, steps=None, warmup=None):
+    """Warm up, then time `steps` decode steps (model step from a HIP graph + the worker's sampling half); returns
+    (seconds for the timed steps, max over ranks; the state)."""
+    from chirrup_amd import ops
+    from chirrup_amd.dist_util import timed_region
+
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    V = 65536
+    state = make_state(model, B)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    tokens = torch.randint(1, V, (B, 1), generator=g, device=dev)
+    if a.no_graph:
+        step_fn = lambda tok: model.forward_seq_batch(tok, state)
+    else:
+        graph = model.capture_decode_graph(state)
+        step_fn = graph.step
+    ids_dev = torch.empty((B,), dtype=torch.int32, device=dev)
+    ids_host = [torch.full((B,), -1, dtype=torch.int32).pin_memory() for _ in range(2)]
+    pending = [None, None]                           # event of the copy into ids_host[i]
+    n_steps = [0]
+    if not a.no_penalties:
+        # the worker's per-slot sampler state (chirrup_amd/worker.py::_init_worker), penalties 0 and decay 1: greedy ids
+        # are unchanged, the tables are read and written like in production
+        f32 = dict(dtype=torch.float32, device=dev)
+        occurrence, alpha_presence = torch.zeros((B, V), **f32), torch.zeros((B, V), **f32)
+        decay = torch.ones((B,), dtype=torch.float16, device=dev)
+        freq = torch.zeros((B,), dtype=torch.float16, device=dev)
+        presence = torch.zeros((B, 1), **f32)
+        penalty_weight = torch.ones((V,), **f32)
+        last_ids = torch.zeros((B,), dtype=torch.int32, device=dev)
+        slots = torch.arange(B, dtype=torch.int32, device=dev)
+        slots64 = slots.long()
+
+    def one_step(tok):
+        """Like Worker.step() with run-ahead: the sampled ids feed the next step on the device; the host receives
+        every step's ids through an asynchronous copy and consumes them one step behind."""
+        logits = step_fn(tok)
+        if a.no_penalties:
+            ops.penalize_argmax(logits, out=ids_dev)     # plain arg-max (temperature 0, samplers.py:195-197)
+        else:
+            ops.penalize_argmax(logits, occurrence, alpha_presence, decay, freq, slots, out=ids_dev)
+            il = ids_dev.long()                          # Worker._commit_sampled
+            last_ids.index_copy_(0, slots64, ids_dev)
+            occurrence.index_put_((slots64, il), penalty_weight[il], accumulate=True)
+            alpha_presence[slots64, il] = presence[slots64, 0]
+        i = n_steps[0] & 1
+        if a.sync_ids:
+            ids_host[i].copy_(ids_dev, non_blocking=False)
+        else:
+            ids_host[i].copy_(ids_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            prev = pending[i ^ 1]
+            if prev is not None:                     # the previous step's ids: on the host before this step ends
+                prev.synchronize()
+                assert int(ids_host[i ^ 1][0]) >= 0
+            pending[i] = ev
+        n_steps[0] += 1
+        return ids_dev.view(B, 1)
+
+    cur = [tokens]
+
+    def timed_step():
+        cur[0] = one_step(cur[0])
+
+    for _ in range(warmup):
+        timed_step()
+    return timed_region(timed_step, steps, dev), state      # barrier + sync on both sides, max over ranks
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -284,59 +437,30 @@ def main():
         model.group_tmix_gemms = bool(a.group_tmix)
     if a.skinny_lora_up is not None:
         model.skinny_lora_up = bool(a.skinny_lora_up)
-    state = make_state(model, B)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-    tokens = torch.randint(1, 65536, (B, 1), generator=g, device=dev)
-
-    if a.no_graph:
-        step_fn = lambda tok: model.forward_seq_batch(tok, state)
-    else:
-        graph = model.capture_decode_graph(state)
-        step_fn = graph.step
-
-    from chirrup_amd import ops
-
-    ids_dev = torch.empty((B,), dtype=torch.int32, device=dev)
-    ids_host = [torch.full((B,), -1, dtype=torch.int32).pin_memory() for _ in range(2)]
-    pending = [None, None]                           # event of the copy into ids_host[i]
-    n_steps = [0]
-
-    def one_step(tok):
-        """Like Worker.step() with run-ahead: the sampled ids feed the next step on the device; the host receives
-        every step's ids through an asynchronous copy and consumes them one step behind."""
-        logits = step_fn(tok)
-        ops.penalize_argmax(logits, out=ids_dev)     # greedy (temperature 0, samplers.py:195-197), penalties 0
-        i = n_steps[0] & 1
-        if a.sync_ids:
-            ids_host[i].copy_(ids_dev, non_blocking=False)
-        else:
-            ids_host[i].copy_(ids_dev, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            prev = pending[i ^ 1]
-            if prev is not None:                     # the previous step's ids: on the host before this step ends
-                prev.synchronize()
-                assert int(ids_host[i ^ 1][0]) >= 0
-            pending[i] = ev
-        n_steps[0] += 1
-        return ids_dev.view(B, 1)
-
-    from chirrup_amd.dist_util import timed_region
-
-    cur = [tokens]
-
-    def timed_step():
-        cur[0] = one_step(cur[0])
-
-    for _ in range(a.warmup):
-        timed_step()
-    dt = timed_region(timed_step, a.steps, dev)       # barrier + sync on both sides, max over ranks
+    dt, state = timed_decode(model, B, a, dev, rank)
 
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
     wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
-    gemm_ms = gemm_event_timing(model, B)
+    gemm_t = gemm_shape_timings(model, B) if rank == 0 else {}
+    mm8_obj = None
+    if rank == 0 and world == 1 and not a.mm8 and not a.no_mm8_leg and not a.no_fused:
+        # the int8 channel-mix path north_star names: the same step with uint8 (w8a16) FFN weights (second model, same seed)
+        del state
+        m8 = build_model(a.model, dev, fused=True, mm8=True, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
+        m8.gemm_splits.update(model.gemm_splits)
+        dt8, st8 = timed_decode(m8, B, a, dev, rank, steps=max(8, a.steps // 2))
+        t8 = gemm_shape_timings(m8, B)
+        mm8_obj = {"ms_per_step": round(dt8 / max(8, a.steps // 2) * 1e3, 4), "dtype": "f16 activations, u8 ffn.key / ffn.value weights (w8a16)",
+                   "algorithmic_bytes": "N*M + 4(N+M) + 2B(N+M) per GEMM (SURVEY 8d)"}
+        for k_ in ("ffn_key_u8", "ffn_value_u8"):
+            if k_ in t8:
+                ms, nb, what = t8[k_]
+                mm8_obj[k_] = {"launch_us": round(ms * 1e3, 2), "algorithmic_bytes": nb, "achieved": round(nb / (ms * 1e-3) / 1e9, 1),
+                               "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "what": what}
+        del m8, st8
+        torch.cuda.empty_cache()
+        state = make_state(model, B)
     if rank == 0:
         ms_per_step = dt / a.steps * 1e3
         value = world * B * a.steps / dt
@@ -359,7 +483,7 @@ def main():
             "dtype": "f16" if not a.mm8 else "f16 (u8 ffn weights, mm8)", "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
-                                   "greedy decode step incl. sampling and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",
+                                   "greedy decode step incl. " + ("plain arg-max" if a.no_penalties else "the worker's penalty tables, fused arg-max and device-side id commit") + " and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",
                        "graph": not a.no_graph, "fused_elementwise": not a.no_fused,
                        "tiled_weight_copies": bool(model.tiled_weights and model._layers[0].rkv_t is not None)},
@@ -373,14 +497,11 @@ def main():
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if gemm_ms is not None:
-            # the kernel with the largest share of the step: algorithmic bytes = the weight once + x in + fp32 partials out
-            gb = 4 * C * C * 2 + B * 4 * C * 2 + 8 * B * C * 4
-            out["gemm_roofline"] = {"bound": "hbm", "kernel": "skinny_gemm_ring_kernel at the ffn.value shape (split 8, fp32 partials)",
-                                    "bytes_per_launch": gb, "launch_us": round(gemm_ms * 1e3, 2),
-                                    "achieved": round(gb / (gemm_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(gb / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches_per_step": 4 * L,
-                                    "note": "four launches of this kernel per layer (R/K/V+LoRA, att.output, ffn.key, ffn.value)"}
+        if gemm_t:
+            out["gemm_roofline"] = gemm_roofline_object(gemm_t, L)
+        if mm8_obj is not None:
+            mm8_obj["vs_fp16_step"] = round(mm8_obj["ms_per_step"] / ms_per_step, 4)
+            out["mm8"] = mm8_obj
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.model, B, a.cpu_layers)
         print(json.dumps(out), flush=True)

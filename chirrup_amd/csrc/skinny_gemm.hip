@@ -10,12 +10,15 @@
 // through LDS-DMA whatever the source, and every workgroup needs all M rows of x beside its W tile.
 //
 // Both kernels: a 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA (global_load_lds_dwordx4) into rings --
-// x image MT*32 rows x 128 B, W image BN rows x 128 B (u8: 64 B), XOR-swizzled on the SOURCE address so that the
+// x image MT*16 rows x 128 B, W image BN rows x 128 B (u8: 64 B), XOR-swizzled on the SOURCE address so that the
 // ds_read_b128 of the MFMA fragments are conflict-free.  No load of the main loop has a register destination, so hand-
 // placed `s_waitcnt vmcnt(n)` + one raw `s_barrier` per K-block keep whole stages in flight across the barrier.
-// A compute wave owns 32 rows of W: v_mfma_f32_32x32x16_f16 with A = W tile (32 n x 16 k), B = x^T (16 k x 32 m); one W
-// fragment feeds MT = ceil(M/32) MFMAs (u8 -> f16 by v_perm in registers).  K is consumed in a permuted order inside each
-// 64-block (lane half h takes k = 32h + 8s + j at MFMA step s) -- the same permutation on both operands.
+// A compute wave owns 32 rows of W as two 16-row tiles: v_mfma_f32_16x16x32_f16 with A = W tile (16 n x 32 k), B = x^T
+// (32 k x 16 m); one x fragment feeds two MFMAs, one W fragment MT = ceil(M/16) of them (u8 -> f16 by v_perm in
+// registers).  16-row tiles because these launches are POWER-bound (profiles/r02_gemm_experiments.txt: the chip runs
+// the main loop at 1.36 GHz, 2.1 GHz with either the MFMAs or the loads alone): M = 200 pads to 208 rows instead of 224
+// (-7 % MFMAs, fragment reads and x bytes), and the 16x16x32 shape delivers more flops per joule than 32x32x16
+// (MI355X_MICROARCH.md, DVFS give-back item 7).
 //
 // wide_gemm_kernel (BN = 256): 8 compute waves, two per SIMD; waves 0-3 also issue the x loads of the NEXT K-block
 //     (L2-resident, 2 slots) at the start of an iteration, waves 4-7 the W loads two K-blocks ahead (HBM, `nt`, 3 slots)
@@ -45,11 +48,9 @@ typedef f16 f16x2 __attribute__((ext_vector_type(2)));
 typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef f16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
 constexpr int kKB = 64;          // K-block
@@ -155,52 +156,115 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
     return t;
 }
 
-// One LDS-DMA instruction (1 KiB per wave) of a W tile image: chunk gi (0 .. 1023 for binary16, 0 .. 511 for uint8) of the
-// 128-row tile `tile_row0 / 128` at K-block k0 / 64, to the wave-uniform LDS address dst (+ lane * 16 by the hardware).
-// Tile-image weights: the image is stored contiguously in LDS order, so the instruction reads 1 KiB of consecutive
-// memory; row-major weights: eight (four) 128-B (64-B) pieces of rows ldw apart, chunk order permuted on the source.
+// LDS-DMA loads of both kernels: `buffer_load_dwordx4 ... lds` through a buffer descriptor -- one 32-bit lane offset per
+// operand for the whole kernel, everything that changes per instruction in the scalar offset (a compute wave carries
+// 26-32 accumulator tiles and has no registers to spare for 64-bit addresses; hoisted 64-bit address arithmetic of the
+// global_load_lds form spilled), and rows past the end of an operand read as zeros (descriptor bounds) instead of
+// needing a clamp.  One instruction moves 1 KiB per wave: a "round" = 256 lanes (4 waves) = 4 KiB.
+//   x round i   : rows 32 i .. 32 i + 31 of the K-block image; chunk g = 256 i + lt is row m = g >> 3, logical 16-B chunk
+//                 (g & 7) ^ ((m >> 1) & 7) -- the XOR term does not depend on i, so round i is round 0 plus 32 rows.
+//   W round     : 32 rows (uint8: 64 rows) of a 128-row tile image; tile-image weights are read linearly (the image is
+//                 stored in LDS order: 1 KiB of consecutive memory per instruction), row-major rows like x
+//                 (uint8: 4 chunks per 64-B row, chunk position ^ ((row >> 2) & 3)).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes < 0xffffffffll ? (int)bytes : (int)0xffffffff, 0x00020000);
+}
+
 template <bool W8>
-__device__ __forceinline__ void glds_w_chunk(const void *W, const bool w_tiled, const int64_t ldw, const int K, const int Np,
-                                             const int tile_row0, const int k0, const int gi, unsigned char *dst) {
-    if constexpr (W8) {                                // 64-B rows: 4 chunks per row, chunk position ^ ((row>>2)&3)
-        const int nr = gi >> 2;
-        const int lc = (gi & 3) ^ ((nr >> 2) & 3);
-        int n = tile_row0 + nr;
-        n = n < Np ? n : Np - 1;
-        const int tr = tile_row0 < Np ? tile_row0 : 0;       // (a 256-wide group whose second tile does not exist re-reads tile 0)
-        const uint8_t *src = w_tiled ? static_cast<const uint8_t *>(W) + ((int64_t)(tr / kTileRows) * (K / kKB) + k0 / kKB) * (kTileRows * kKB) + gi * 16
-                                     : static_cast<const uint8_t *>(W) + (int64_t)n * ldw + k0 + lc * 16;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 2);           // streamed once -> nt
-    } else {
-        const int nr = gi >> 3;
-        const int lc = (gi & 7) ^ ((nr >> 1) & 7);
-        int n = tile_row0 + nr;
-        n = n < Np ? n : Np - 1;
-        const int tr = tile_row0 < Np ? tile_row0 : 0;
-        const f16 *src = w_tiled ? static_cast<const f16 *>(W) + ((int64_t)(tr / kTileRows) * (K / kKB) + k0 / kKB) * (kTileRows * kKB) + gi * 8
-                                 : static_cast<const f16 *>(W) + (int64_t)n * ldw + k0 + lc * 8;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 2);
+struct Loader {
+    static constexpr int kEl = W8 ? 1 : 2;                       // bytes per weight element
+    static constexpr int kWTile = kTileRows * kKB * kEl;         // one 128-row tile image: 16 KiB (uint8: 8 KiB)
+    static constexpr int kRoundsPerTile = kWTile / 4096;
+    static constexpr int kRowsPerRound = W8 ? 64 : 32;
+    __amdgpu_buffer_rsrc_t xsrc, wsrc;
+    int xoff, woff, ldx, K, Np;
+    int64_t ldw;
+    bool w_tiled;
+
+    __device__ __forceinline__ Loader(const Tile &t, int M, int ldx_, int64_t ldw_, int K_, int lt)
+        : xsrc(make_rsrc(t.X, (int64_t)M * ldx_ * 2)),
+          wsrc(make_rsrc(t.W, t.w_tiled ? (int64_t)t.Np * K_ * kEl : (int64_t)t.Np * ldw_ * kEl)),
+          ldx(ldx_), K(K_), Np(t.Np), ldw(ldw_), w_tiled(t.w_tiled) {
+        xoff = ((lt >> 3) * ldx_ + (((lt & 7) ^ ((lt >> 4) & 7)) << 3)) * 2;
+        const int wrow = W8 ? (lt >> 2) : (lt >> 3);
+        const int wlc = W8 ? ((lt & 3) ^ ((wrow >> 2) & 3)) : ((lt & 7) ^ ((wrow >> 1) & 7));
+        woff = t.w_tiled ? lt * 16 : (int)((wrow * ldw_) * kEl + wlc * 16);
+    }
+    // dst: the wave's 1 KiB of the round's 4 KiB in LDS (wave-uniform)
+    __device__ __forceinline__ void x_round(int i, int k0, unsigned char *dst) const {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)dst, 16, xoff, (i * 32 * ldx + k0) * 2, 0, 0);
+    }
+    __device__ __forceinline__ void w_round(int tile_row0, int round, int k0, unsigned char *dst) const {   // streamed once -> nt
+        unsigned soff;
+        if (w_tiled) {
+            if (tile_row0 >= Np) tile_row0 = 0;        // (a 256-wide group whose second tile does not exist re-reads a valid one)
+            soff = (unsigned)(((tile_row0 / kTileRows) * (K / kKB) + k0 / kKB) * kWTile + round * 4096);
+        } else {
+            soff = (unsigned)(((int64_t)(tile_row0 + round * kRowsPerRound) * ldw + k0) * kEl);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)dst, 16, woff, (int)soff, 0, 2);
+    }
+};
+
+// MFMA tiling of one K-block for one compute wave (32 W rows x MT 16-row tiles of x):
+//   v_mfma_f32_16x16x32_f16: A = W[16 n][32 k], B = x^T[32 k][16 m]; lane l = (c = l & 15, q = l >> 4) supplies
+//   A[n = c][k = 8q .. 8q+7] and B[k = 8q .. 8q+7][m = c], i.e. one 16-B chunk of a row of either LDS image; it receives
+//   D[n = 4q + i][m = c] in accumulator register i.
+// W fragments of lane (c, q): rows row0 + 16 nt + c (nt = 0, 1) of the 128-row tile image at wt, k-step ks = 0, 1.
+template <bool W8>
+__device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int row0, const int c, const int q, f16x8 (&wf)[2][2]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) {
+        const int row = row0 + 16 * nt + c;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            if constexpr (W8) {
+                // bytes 32 ks + 8q .. +8 of a 64-B row: 16-B chunk 2 ks + (q >> 1) (position ^ ((row >> 2) & 3)), half q & 1
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(wt + row * 64 + (((2 * ks + (q >> 1)) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8);
+                const f16x2 a = cvt_u8x2(v[0], 1), b = cvt_u8x2(v[0], 0), cc = cvt_u8x2(v[1], 1), d = cvt_u8x2(v[1], 0);
+                wf[nt][ks] = (f16x8){a.x, a.y, b.x, b.y, cc.x, cc.y, d.x, d.y};
+            } else {
+                wf[nt][ks] = *reinterpret_cast<const f16x8 *>(wt + row * 128 + (((4 * ks + q) ^ ((row >> 1) & 7)) << 4));
+            }
+        }
     }
 }
 
-// The four W fragments (k steps) of lane (r, h) for in-tile row `row` of the tile image at wt.
-template <bool W8>
-__device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int row, const int h, f16x8 (&wf)[4]) {
-    if constexpr (W8) {
-        // lane (r,h) needs bytes 32h .. 32h+31 of its row: chunks 2h and 2h+1
-        const int sw = (row >> 2) & 3;
-        const u32x4 q0 = *reinterpret_cast<const u32x4 *>(wt + row * 64 + (((2 * h) ^ sw) << 4));
-        const u32x4 q1 = *reinterpret_cast<const u32x4 *>(wt + row * 64 + (((2 * h + 1) ^ sw) << 4));
+// One K-block of MFMAs for one wave: acc[nt][mt] += W tile nt . x tile mt over 64 k.  The x fragments are fetched one
+// group (half of the m-tiles of one k-step) ahead of the MFMAs that use them; the sched_barriers pin that order -- left
+// alone, the scheduler sinks every ds_read to just before its MFMA (fewer live registers) and each MFMA then waits a full
+// LDS latency.  `mid()` runs between the two k-steps (the wide kernel issues its W loads there).
+template <int MT, typename Mid>
+__device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 (&wf)[2][2], const int c, const int q, f32x4 (&acc)[2][MT],
+                                           Mid &&mid) {
+    constexpr int HA = (MT + 1) / 2, HB = MT - HA;     // m-tiles of the two groups of a k-step
+    auto xfrag = [&](int ks, int mt) {
+        const int m = mt * 16 + c;
+        return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * ks + q) ^ ((m >> 1) & 7)) << 4));
+    };
+    f16x8 bq[2][HA];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const uint32_t lo = s < 2 ? q0[2 * s] : q1[2 * (s - 2)];
-            const uint32_t hi = s < 2 ? q0[2 * s + 1] : q1[2 * (s - 2) + 1];
-            const f16x2 a = cvt_u8x2(lo, 1), b = cvt_u8x2(lo, 0), c = cvt_u8x2(hi, 1), d = cvt_u8x2(hi, 0);
-            wf[s] = (f16x8){a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
+    for (int j = 0; j < HA; j++) bq[0][j] = xfrag(0, j);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {                      // group g: k-step g >> 1, m-tiles [first, first + count)
+        const int ks = g >> 1, first = (g & 1) ? HA : 0, count = (g & 1) ? HB : HA;
+        if (g + 1 < 4) {
+            const int nks = (g + 1) >> 1, nfirst = ((g + 1) & 1) ? HA : 0, ncount = ((g + 1) & 1) ? HB : HA;
+#pragma unroll
+            for (int j = 0; j < ncount; j++) bq[(g + 1) & 1][j] = xfrag(nks, nfirst + j);
         }
-    } else {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g == 2) {
+            mid();
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-        for (int s = 0; s < 4; s++) wf[s] = *reinterpret_cast<const f16x8 *>(wt + row * 128 + (((4 * h + s) ^ ((row >> 1) & 7)) << 4));
+        for (int j = 0; j < count; j++) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++)
+                acc[nt][first + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][ks], bq[g & 1][j], acc[nt][first + j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -235,24 +299,21 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
     }
 }
 
-// acc[mt][i] of the wave that owns staged columns col0 .. col0+31: m = mt*32 + (lane & 31), n = col0 + 8*(i>>2) + 4*h + (i&3)
+// accumulators of the wave that owns staged columns col0 .. col0+31: acc[nt][mt][i] is m = 16 mt + c, n = col0 + 16 nt + 4q + i
 template <int MT>
-__device__ __forceinline__ void stage_acc(float *stage, const f32x16 (&acc)[MT], const int M, const int col0, const int r, const int h) {
+__device__ __forceinline__ void stage_acc(float *stage, const f32x4 (&acc)[2][MT], const int M, const int col0, const int c, const int q) {
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        const int m = mt * 32 + r;
+        const int m = mt * 16 + c;
         if (m >= M) continue;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const f32x4 o = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-            *reinterpret_cast<f32x4 *>(stage + m * kLd + col0 + 8 * g + 4 * h) = o;
-        }
+        for (int nt = 0; nt < 2; nt++) *reinterpret_cast<f32x4 *>(stage + m * kLd + col0 + 16 * nt + 4 * q) = acc[nt][mt];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // BN = 128: four compute waves + four dedicated loader waves, one ring of D slots for both operands (each loader wave
-// issues its quarter of the x and of the W stage and waits for it with one counted vmcnt).
+// issues its quarter of the x and of the W stage and waits for it with one counted vmcnt).  MT = 16-row tiles of x.
 // (Measured and dropped, profiles/r02_gemm_experiments.txt: x and W loader roles on two waves each with a deeper W ring
 // -- 6x slower, a loader wave that has to wait for its whole x stage every K-block is the critical path.)
 template <int MT, bool W8, int EPI>
@@ -262,15 +323,16 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BN = 128, D = W8 ? 4 : 3;
-    constexpr int kXBytes = MT * 32 * 128;            // x K-block image
+    constexpr int kXBytes = MT * 16 * 128;            // x K-block image
     constexpr int kWBytes = BN * (W8 ? 64 : 128);     // W K-block image: 128 rows x 64 k (binary16 or uint8)
-    constexpr int kXLoads = kXBytes / 16 / 256;       // LDS-DMA instructions per loader lane per stage
+    constexpr int kXRounds = (MT + 1) / 2;            // rounds of 256 lanes x 16 B = 32 rows; the last one is half a round when MT is odd
     constexpr int kWLoads = kWBytes / 16 / 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, q = lane >> 4;
     const bool computes = wave < 4;
     const int lt = tid & 255, lw = wave & 3;
+    const bool short_x = (MT & 1) && lw >= 2;         // this loader wave sits out the half round
     const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
     const int n_base = t.ngroup * BN;
     const int n0 = n_base + wave * 32;
@@ -281,51 +343,23 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
     unsigned char *const xring = smem, *const wring = smem + D * kXBytes;
 
-    f32x16 acc[MT];
+    f32x4 acc[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
+        for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    const Loader<W8> ld(t, M, ldx, ldw, K, lt);
     auto stage = [&](int kb) {
         const int k0 = k_begin + kb * kKB;
         unsigned char *xb = xring + (kb % D) * kXBytes, *wb = wring + (kb % D) * kWBytes;
 #pragma unroll
-        for (int i = 0; i < kXLoads; i++) {
-            const int g = i * 256 + lt;
-            int m = g >> 3;
-            const int lc = (g & 7) ^ ((m >> 1) & 7);
-            m = m < M ? m : M - 1;
-            __builtin_amdgcn_global_load_lds((gptr_t)(t.X + (int64_t)m * ldx + k0 + lc * 8), (lptr_t)(xb + (i * 256 + lw * 64) * 16), 16, 0, 0);
+        for (int i = 0; i < kXRounds; i++) {
+            if (i == kXRounds - 1 && short_x) break;
+            ld.x_round(i, k0, xb + (i * 256 + lw * 64) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < kWLoads; i++)
-            glds_w_chunk<W8>(t.W, t.w_tiled, ldw, K, t.Np, n_base, k0, i * 256 + lt, wb + (i * 256 + lw * 64) * 16);
-    };
-    auto compute = [&](int kb) {
-        const unsigned char *xt = xring + (kb % D) * kXBytes;
-        f16x8 wf[4];
-        read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32 + r, h, wf);
-        auto bfrag = [&](int s, int mt) {
-            const int m = mt * 32 + r;
-            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
-        };
-        // x fragments one MFMA group ahead of their use.  The sched_barriers pin that order: left alone, the scheduler
-        // sinks every ds_read to just before its MFMA (fewer live registers) and each MFMA then waits a full LDS latency.
-        f16x8 bq[2][MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) bq[0][mt] = bfrag(0, mt);
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (s + 1 < 4) {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) bq[(s + 1) & 1][mt] = bfrag(s + 1, mt);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], bq[s & 1][mt], acc[mt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        for (int i = 0; i < kWLoads; i++) ld.w_round(n_base, i, k0, wb + (i * 256 + lw * 64) * 16);
     };
 
     // at step kb the ring holds stages kb .. kb+D-2, in issue order
@@ -335,62 +369,50 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
             if (p < nkb) stage(p);
     }
     for (int kb = 0; kb < nkb; kb++) {
-        const int left = nkb - 1 - kb;
-        if (!computes) wait_stages_ahead<kXLoads + kWLoads>(left < D - 2 ? left : D - 2);
+        if (!computes) {
+            const int left = nkb - 1 - kb, ahead = left < D - 2 ? left : D - 2;
+            if (short_x) wait_stages_ahead<kXRounds - 1 + kWLoads>(ahead);
+            else wait_stages_ahead<kXRounds + kWLoads>(ahead);
+        }
         asm volatile("s_barrier" ::: "memory");        // every loader's share landed; the slot restaged below is no longer read
         if (!computes) {
             if (kb + D - 1 < nkb) stage(kb + D - 1);
         } else {
-            compute(kb);
+            f16x8 wf[2][2];
+            read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
+            mma_kblock<MT>(xring + (kb % D) * kXBytes, wf, c, q, acc, [] {});
         }
     }
     if (!computes) return;                             // loader waves are done; finished waves do not count in s_barrier
-    float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*32 rows x 528 B <= its size)
+    float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*16 rows x 528 B <= its size)
     __syncthreads();                                   // every compute wave is past its last fragment read
-    if (wave_live) stage_acc<MT>(stg, acc, M, wave * 32, r, h);
+    if (wave_live) stage_acc<MT>(stg, acc, M, wave * 32, c, q);
     __syncthreads();
     store_staged<EPI, 256>(stg, M, n_base, t, t.kslice, bs.relu_sq);
 }
 
 // ------------------------------------------------------------------------------------------------
 // BN = 256: eight compute waves (two per SIMD).  Waves 0-3 issue the x loads (next K-block, 2 slots) at the start of an
-// iteration, waves 4-7 the W loads (WD-1 K-blocks ahead, WD slots) between the two halves of their MFMAs.
-// The loads are `buffer_load_dwordx4 ... lds` (LDS-DMA through a buffer descriptor): one 32-bit lane offset per role for the
-// whole kernel, everything that changes per instruction in the scalar offset -- the wave carries 7-8 accumulator tiles and
-// has no registers to spare for 64-bit addresses -- and rows past the end of an operand read as zeros (descriptor bounds)
-// instead of needing a clamp.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes < 0xffffffffll ? (int)bytes : (int)0xffffffff, 0x00020000);
-}
-
+// iteration, waves 4-7 the W loads (WD-1 K-blocks ahead, WD slots) between the two k-steps of their MFMAs.
 template <int MT, bool W8, int EPI>
 __global__ __launch_bounds__(512) void wide_gemm_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
     const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
     const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifndef WIDE_WD
-#define WIDE_WD 3              // tools/ builds vary the W ring depth and where the W loads are issued
-#endif
-#ifndef WIDE_W_ISSUE_STEP
-#define WIDE_W_ISSUE_STEP 2
-#endif
-#ifndef WIDE_EXP
-#define WIDE_EXP 0             // timing experiments: 1 no MFMA (fragments still read), 2 no fragment reads either, 4 no loads, 8 no epilogue
-#endif
-    constexpr int BN = 256, XD = 2, WD = W8 ? 5 : WIDE_WD;
-    constexpr int kEl = W8 ? 1 : 2;                    // bytes per weight element
-    constexpr int kXBytes = MT * 32 * 128;
-    constexpr int kWTile = kTileRows * kKB * kEl;      // one 128-row tile image: 16 KiB (uint8: 8 KiB)
+    constexpr int BN = 256, XD = 2, WD = W8 ? 5 : 3;
+    constexpr int kXBytes = MT * 16 * 128;
+    constexpr int kWTile = Loader<W8>::kWTile;         // one 128-row tile image: 16 KiB (uint8: 8 KiB)
     constexpr int kWBytes = 2 * kWTile;
-    constexpr int kXLoads = MT;                        // per x-loader wave: 4 waves x 1 KiB per round
+    constexpr int kXRounds = (MT + 1) / 2;             // per x-loader wave: rounds of 4 waves x 1 KiB (32 rows); half a round last when MT is odd
     constexpr int kWLoads = kWBytes / 16 / 256;        // per W-loader wave: 8 (uint8: 4)
     constexpr int kPerTile = kWLoads / 2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, h = lane >> 5;
+    const int c = lane & 15, q = lane >> 4;
     const bool xrole = wave < 4;
     const int lt = tid & 255, lw = wave & 3;
+    const bool short_x = (MT & 1) && lw >= 2;
     const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
     const int n_base = t.ngroup * BN;
     const int n0 = n_base + wave * 32;
@@ -401,54 +423,33 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
     const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
     unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
 
-    // x: chunk g = i*256 + lt of the image is row m = g >> 3 (= 32 i + (lt >> 3)), logical 16-B chunk (g & 7) ^ ((m >> 1) & 7)
-    // -- the XOR term does not depend on i, so round i is round 0 plus 32 rows.
-    const __amdgpu_buffer_rsrc_t xsrc = make_rsrc(t.X, (int64_t)M * ldx * 2);
-    const int xoff = ((lt >> 3) * ldx + (((lt & 7) ^ ((lt >> 4) & 7)) << 3)) * 2;
-    // W: tile images are read linearly; row-major rows like x (uint8: 4 chunks per 64-B row, XOR ((row >> 2) & 3))
-    const __amdgpu_buffer_rsrc_t wsrc = make_rsrc(t.W, t.w_tiled ? (int64_t)t.Np * K * kEl : (int64_t)t.Np * ldw * kEl);
-    const int wrow = W8 ? (lt >> 2) : (lt >> 3);
-    const int wlc = W8 ? ((lt & 3) ^ ((wrow >> 2) & 3)) : ((lt & 7) ^ ((wrow >> 1) & 7));
-    const int woff = t.w_tiled ? lt * 16 : (int)((wrow * ldw) * kEl + wlc * 16);
-    const int rows_per_round = W8 ? 64 : 32;           // rows of a tile image that one round of 256 lanes covers
+    const Loader<W8> ld(t, M, ldx, ldw, K, lt);
 
-    f32x16 acc[MT];
+    f32x4 acc[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++)
+    for (int nt = 0; nt < 2; nt++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[mt][i] = 0.f;
-#if WIDE_EXP & 16      // clock stamps (shader cycles / 100 MHz ticks) around the main loop, into plane 15 of the partial buffer
-    const uint64_t st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
+        for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto stage_x = [&](int kb) {
         const int k0 = k_begin + kb * kKB;
         unsigned char *xb = xring + (kb % XD) * kXBytes;
 #pragma unroll
-        for (int i = 0; i < kXLoads; i++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lptr_t)(xb + (i * 256 + lw * 64) * 16), 16, xoff, (i * 32 * ldx + k0) * 2, 0, 0);
+        for (int i = 0; i < kXRounds; i++) {
+            if (i == kXRounds - 1 && short_x) break;
+            ld.x_round(i, k0, xb + (i * 256 + lw * 64) * 16);
+        }
     };
-    auto stage_w = [&](int kb) {                       // streamed once -> nt
+    auto stage_w = [&](int kb) {
         const int k0 = k_begin + kb * kKB;
         unsigned char *wb = wring + (kb % WD) * kWBytes;
 #pragma unroll
-        for (int i = 0; i < kWLoads; i++) {
-            const int tile = i / kPerTile, round = i % kPerTile;
-            int row0 = n_base + tile * kTileRows;
-            unsigned soff;
-            if (t.w_tiled) {
-                if (row0 >= t.Np) row0 = n_base;       // a 256-wide group whose second tile does not exist re-reads the first
-                soff = (unsigned)(((row0 / kTileRows) * (K / kKB) + k0 / kKB) * kWTile + round * 4096);
-            } else {
-                soff = (unsigned)(((int64_t)(row0 + round * rows_per_round) * ldw + k0) * kEl);
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lptr_t)(wb + (i * 256 + lw * 64) * 16), 16, woff, (int)soff, 0, 2);
-        }
+        for (int i = 0; i < kWLoads; i++)
+            ld.w_round(n_base + (i / kPerTile) * kTileRows, i % kPerTile, k0, wb + (i * 256 + lw * 64) * 16);
     };
 
     // at step kb: the x ring holds stage kb, the W ring stages kb .. kb+WD-2, each in issue order of its loader waves
-    if (WIDE_EXP & 4) {
-    } else if (xrole) {
+    if (xrole) {
         if (nkb > 0) stage_x(0);
     } else {
 #pragma unroll
@@ -460,68 +461,19 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
         if (xrole) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else wait_stages_ahead<kWLoads>(left < WD - 2 ? left : WD - 2);
         asm volatile("s_barrier" ::: "memory");        // stage kb of both operands landed; the slots restaged below are no longer read
-        if (!(WIDE_EXP & 4) && xrole && kb + 1 < nkb) stage_x(kb + 1);
+        if (xrole && kb + 1 < nkb) stage_x(kb + 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (WIDE_EXP & 2) {
-            if (!(WIDE_EXP & 4) && !xrole && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
-            continue;
-        }
-        const unsigned char *xt = xring + (kb % XD) * kXBytes;
-        f16x8 wf[4];
-        read_w_frags<W8>(wring + (kb % WD) * kWBytes + (wave >> 2) * kWTile, (wave & 3) * 32 + r, h, wf);
-        auto bfrag = [&](int s, int mt) {
-            const int m = mt * 32 + r;
-            return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * h + s) ^ ((m >> 1) & 7)) << 4));
-        };
-        // x fragments one MFMA group ahead of their use (pinned with sched_barrier: left alone, the scheduler sinks every
-        // ds_read to just before its MFMA and each MFMA then waits a full LDS latency)
-        f16x8 bq[2][MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++) bq[0][mt] = bfrag(0, (WIDE_EXP & 32) ? (mt & ~1) : mt);   // exp 32: half the x fragment reads (timing only)
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            if (s + 1 < 4) {
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++) {
-                    if ((WIDE_EXP & 32) && (mt & 1)) bq[(s + 1) & 1][mt] = bq[(s + 1) & 1][mt - 1];
-                    else bq[(s + 1) & 1][mt] = bfrag(s + 1, mt);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (s == WIDE_W_ISSUE_STEP) {              // W loaders: between the halves of their MFMAs, when the x loaders are back to computing
-                if (!(WIDE_EXP & 4) && !xrole && kb + WD - 1 < nkb) stage_w(kb + WD - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                if (WIDE_EXP & 1) asm volatile("" ::"v"(wf[s]), "v"(bq[s & 1][mt]));
-                else acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[s], bq[s & 1][mt], acc[mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-#if WIDE_EXP & 16
-    if (EPI == EPI_PARTIAL && tid == 0) {
-        const uint64_t st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-        uint32_t *dbg = reinterpret_cast<uint32_t *>(t.part + (int64_t)15 * M * t.Np) + (blockIdx.x + gridDim.x * blockIdx.y) * 2;
-        dbg[0] = (uint32_t)(st_c1 - st_c0), dbg[1] = (uint32_t)(st_r1 - st_r0);
-    }
-#endif
-    if (WIDE_EXP & 8) {
-        float tsum = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) tsum += acc[mt][i];
-        if (tsum == 12345.678f) t.part[0] = tsum;
-        return;
+        f16x8 wf[2][2];
+        read_w_frags<W8>(wring + (kb % WD) * kWBytes + (wave >> 2) * kWTile, (wave & 3) * 32, c, q, wf);
+        // W loaders: between the k-steps of their MFMAs, when the x loaders are back to computing
+        mma_kblock<MT>(xring + (kb % XD) * kXBytes, wf, c, q, acc, [&] { if (!xrole && kb + WD - 1 < nkb) stage_w(kb + WD - 1); });
     }
     // ---- epilogue: two passes of 128 columns through a row-major LDS staging area (the rings are no longer needed)
     float *stg = reinterpret_cast<float *>(smem);
     __syncthreads();                                   // every wave is past its last fragment read (no LDS-DMA is pending)
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        if ((wave >> 2) == half && wave_live) stage_acc<MT>(stg, acc, M, (wave & 3) * 32, r, h);
+        if ((wave >> 2) == half && wave_live) stage_acc<MT>(stg, acc, M, (wave & 3) * 32, c, q);
         __syncthreads();
         store_staged<EPI, 512>(stg, M, n_base + half * kTileRows, t, t.kslice, bs.relu_sq);
         if (half == 0) __syncthreads();
@@ -645,9 +597,9 @@ int pick_splits(int bn, int N, int K, int requested, int Z = 1) {
 }
 
 size_t lds_bytes(int bn, int MT, bool w8) {
-    const size_t x = (size_t)MT * 32 * 128, stage = (size_t)MT * 32 * kLd * sizeof(float);
+    const size_t x = (size_t)MT * 16 * 128, stage = (size_t)MT * 16 * kLd * sizeof(float);
     size_t ring;
-    if (bn == 256) ring = 2 * x + (size_t)(w8 ? 5 : WIDE_WD) * 2 * kTileRows * (w8 ? 64 : 128);
+    if (bn == 256) ring = 2 * x + (size_t)(w8 ? 5 : 3) * 2 * kTileRows * (w8 ? 64 : 128);
     else ring = (size_t)(w8 ? 4 : 3) * (x + (size_t)kTileRows * (w8 ? 64 : 128));
     return ring > stage ? ring : stage;
 }
@@ -677,7 +629,7 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
         if (bn == 256) GO_K(wide_gemm_kernel, MTV);   \
         else GO_K(ring_gemm_kernel, MTV);             \
     } while (0)
-    switch (MT) {
+    switch (MT) {                                      // 16-row tiles of x: M <= 256
         case 1: GO(1); break;
         case 2: GO(2); break;
         case 3: GO(3); break;
@@ -685,7 +637,15 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
         case 5: GO(5); break;
         case 6: GO(6); break;
         case 7: GO(7); break;
-        default: GO(8); break;
+        case 8: GO(8); break;
+        case 9: GO(9); break;
+        case 10: GO(10); break;
+        case 11: GO(11); break;
+        case 12: GO(12); break;
+        case 13: GO(13); break;
+        case 14: GO(14); break;
+        case 15: GO(15); break;
+        default: GO(16); break;
     }
 #undef GO
 #undef GO_K
@@ -770,7 +730,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     const int s = pick_splits(bn, N, K, splits);
     const bool partial = s > 1;                        // unsplit: bias and relu^2 run in the kernel's own epilogue
     if (partial && !workspace) return CHIRRUP_E_NULL;
-    const int MT = (M + 31) / 32;
+    const int MT = (M + 15) / 16;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((N + bn - 1) / bn, s);
     BatchStrides bs{};
@@ -820,7 +780,7 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
     const int s = pick_splits(bn, N, K, splits, Z);
     const bool partial = s > 1 || act != 0;
     if (partial && !workspace) return CHIRRUP_E_NULL;
-    const int MT = (M + 31) / 32;
+    const int MT = (M + 15) / 16;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((N + bn - 1) / bn, s, Z);
     BatchStrides bs{};
@@ -905,7 +865,7 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
         max_n = q.n > max_n ? q.n : max_n;
         gt.first[i + 1] = gt.first[i] + (q.n + bn - 1) / bn;
     }
-    const int MT = (M + 31) / 32;
+    const int MT = (M + 15) / 16;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(gt.first[count], s, 1);
     int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
@@ -927,7 +887,7 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
     if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     const int bn = choose_bn(N);
     const int s = pick_splits(bn, N, K, splits);
-    const int MT = (M + 31) / 32;
+    const int MT = (M + 15) / 16;
     const dim3 grid((N + bn - 1) / bn, s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
@@ -969,7 +929,7 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
     float *S = reinterpret_cast<float *>(ws + off);
     off += 256 * ((Bmax * 3 * 4 + 255) / 256);
     float *part = reinterpret_cast<float *>(ws + off);
-    // The kernels hold at most 256 activation rows per weight pass (8 accumulator tiles per wave): a longer batch
+    // The kernels hold at most 256 activation rows per weight pass (32 accumulator tiles per wave): a longer batch
     // (chunked prefill) is cut into 256-row blocks that re-stream the weights; the blocks reuse the workspace in
     // stream order.
     for (int b0 = 0; b0 < B; b0 += 256) {
@@ -978,7 +938,7 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         f16 *yb = static_cast<f16 *>(y) + (int64_t)b0 * y_stride;
         hipLaunchKernelGGL(mm8_prep_kernel, dim3(bn), dim3(256), 0, st, N_in, xb, x_stride, (const f16 *)ry, (const f16 *)my,
                            xs, S);
-        const int MT = (bn + 31) / 32;
+        const int MT = (bn + 15) / 16;
         const dim3 grid((M_out + bnc - 1) / bnc, s);
         BatchStrides bs{};
         bs.tiled = w_tiled ? 1 : 0;
