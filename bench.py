@@ -213,17 +213,26 @@ def gemm_shape_timings(model, B):
         out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "GEMM kernel + reduce with relu^2")
         out["ffn_value"] = (_replay_time(ffn_value, L), 4 * C * C * 2 + B * 4 * C * 2 + B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
     elif lws[0].f_K8 is not None:
+        pk = torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), B, 4 * C), dtype=torch.float32, device=dev)
+        S = torch.zeros((B, 3), dtype=torch.float32, device=dev)
+        xs2, S2 = torch.empty((B, 4 * C), dtype=torch.float16, device=dev), torch.empty((B, ops.mm8_row_parts(4 * C), 3), dtype=torch.float32, device=dev)
+
         def ffn_key8():
             for lw in lws:
-                ops.mm8t_linear(x_c, *lw.f_K8, act=1, tiled=lw.f8_tiled)
+                ops.mm8t_gemm_partial(x_c, lw.f_K8.qT, 4 * C, gs["ffn_key"], pk, tiled=lw.f8_tiled)
 
         def ffn_value8():
             for lw in lws:
-                ops.mm8t_linear(x_4c, *lw.f_V8, tiled=lw.f8_tiled)
+                ops.mm8t_gemm_partial(x_4c, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled)
+
+        def reduce_rows():
+            for lw in lws:
+                ops.mm8_reduce_rows(pk, lw.f_K8.rx, lw.f_K8.mx, S, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs2, S2))
 
         mm8_bytes = lambda n, m: n * m + 4 * (n + m) + 2 * B * (n + m)
-        out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C), "mm8: activation prologue + u8 GEMM kernel + reduce (rank-1 corrections, relu^2)")
-        out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "mm8: activation prologue + u8 GEMM kernel + reduce (rank-1 corrections)")
+        out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C), "u8 GEMM kernel (fp32 core partials; prologue in the LN kernel, corrections in mm8_reduce_rows)")
+        out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "u8 GEMM kernel (fp32 core partials; prologue in mm8_reduce_rows, corrections in the next LN kernel)")
+        out["mm8_reduce_rows"] = (_replay_time(reduce_rows, L), pk.numel() * 4 + B * 4 * C * 2, "reduce + corrections + relu^2 of ffn.key and the prologue of ffn.value (bytes: partials in, xs out)")
     if model._head_t is not None:
         out["head"] = (_replay_time(lambda: ops.skinny_linear(x_c, model._head_t, splits=1), 1), V * C * 2 + B * C * 2 + B * V * 2,
                        "unsplit GEMM kernel, fp16 epilogue")
@@ -453,7 +462,7 @@ def main():
         t8 = gemm_shape_timings(m8, B)
         mm8_obj = {"ms_per_step": round(dt8 / max(8, a.steps // 2) * 1e3, 4), "dtype": "f16 activations, u8 ffn.key / ffn.value weights (w8a16)",
                    "algorithmic_bytes": "N*M + 4(N+M) + 2B(N+M) per GEMM (SURVEY 8d)"}
-        for k_ in ("ffn_key_u8", "ffn_value_u8"):
+        for k_ in ("ffn_key_u8", "ffn_value_u8", "mm8_reduce_rows"):
             if k_ in t8:
                 ms, nb, what = t8[k_]
                 mm8_obj[k_] = {"launch_us": round(ms * 1e3, 2), "algorithmic_bytes": nb, "achieved": round(nb / (ms * 1e-3) / 1e9, 1),

@@ -58,13 +58,26 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     return t;
 }
 
+// three sums at once (the mm8 prologue's S0, S1, S2): one pair of barriers instead of three
+__device__ __forceinline__ void block_sum3(float &a, float &b, float &c, float *red3) {
+    a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) red3[wid] = a, red3[kLnThreads / 64 + wid] = b, red3[2 * (kLnThreads / 64) + wid] = c;
+    __syncthreads();
+    a = b = c = 0.f;
+#pragma unroll
+    for (int i = 0; i < kLnThreads / 64; i++) a += red3[i], b += red3[kLnThreads / 64 + i], c += red3[2 * (kLnThreads / 64) + i];
+}
+
 // Load row (x + delta) as binary16, return its layer-norm in `out` (binary16 values held as float).
 // If x_out != nullptr the summed row is stored there.
 // x and x_out may alias (the in-place residual update of a decode step), so neither is __restrict__.
 __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
                                        const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
                                        float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
-                                       int dsplits = 0, int64_t dsplit_stride = 0) {
+                                       int dsplits = 0, int64_t dsplit_stride = 0, const f16 *__restrict__ q_rx = nullptr,
+                                       const f16 *__restrict__ q_mx = nullptr, const float *__restrict__ q_S = nullptr) {
     const int nchunk = C >> 3;
     float vals[kLnMaxChunks][8];
     float s = 0.f;
@@ -80,6 +93,14 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                     const float4 p1 = *reinterpret_cast<const float4 *>(dpart + sidx * dsplit_stride + c * 8 + 4);
                     acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w;
                     acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+                }
+                if (q_S) {            // the partials are the core of an mm8 product taken against 1024 + q (skinny_gemm.hip: cvt_u8x2):
+                                      // y = rx*(core - 1024*S0 + 0.5*S0) + S1 + mx*S2 (benchmark.py:167-179)
+                    const f16x8 rxv = *reinterpret_cast<const f16x8 *>(q_rx + c * 8);
+                    const f16x8 mxv = *reinterpret_cast<const f16x8 *>(q_mx + c * 8);
+                    const float s0 = q_S[0], s1 = q_S[1], s2 = q_S[2];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) acc[e] = (float)rxv[e] * (acc[e] - 1023.5f * s0) + s1 + (float)mxv[e] * s2;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)h(acc[e]));
@@ -128,16 +149,29 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int T, const int C, const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
-    const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride) {
-    __shared__ float red[kLnThreads / 64];
+    const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride,
+    const chirrup_mm8_fuse fz) {
+    __shared__ float red[3 * (kLnThreads / 64)];
     const int row = blockIdx.x;
     const int bb = row / T, t = row - bb * T;
     const int64_t slot = slot_idx ? (int64_t)slot_idx[bb] : (int64_t)bb;   // row of the carry tables
     const int nchunk = C >> 3;
     const int64_t ro = (int64_t)row * C;
     float cur[kLnMaxChunks][8];
+    const f16 *q_rx = static_cast<const f16 *>(fz.in_rx), *q_mx = static_cast<const f16 *>(fz.in_mx);
+    __shared__ float qsum[2][3];                      // mm8 row sums of this row and of its predecessor: the parts added up once
+    if (fz.in_S) {
+        if (threadIdx.x < 6) {
+            const int which = threadIdx.x / 3, j = threadIdx.x % 3, r_ = row - which;
+            float tsum = 0.f;
+            if (r_ >= 0)
+                for (int p = 0; p < fz.in_S_parts; p++) tsum += fz.in_S[((int64_t)r_ * fz.in_S_parts + p) * 3 + j];
+            qsum[which][j] = tsum;
+        }
+        __syncthreads();
+    }
     ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
-           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride);
+           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, fz.in_S ? qsum[0] : nullptr);
     if (NMIX == 0) {
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++) {
@@ -165,8 +199,11 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         }
     } else {
         ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red,
-               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride);
+               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride, q_rx, q_mx, fz.in_S ? qsum[1] : nullptr);
     }
+    const f16 *p_ry = static_cast<const f16 *>(fz.out_ry), *p_my = static_cast<const f16 *>(fz.out_my);
+    f16 *p_xs = static_cast<f16 *>(fz.out_xs);
+    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
         const int c = threadIdx.x + q * kLnThreads;
@@ -186,8 +223,25 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
 #pragma unroll
                 for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
                 *reinterpret_cast<f16x8 *>(out + (int64_t)m * out_stride + ro + c * 8) = o;
+                if (NMIX == 1 && p_xs) {      // mm8 activation prologue of the GEMM that consumes `out` (mm8_prep_kernel's arithmetic)
+                    const f16x8 rv = *reinterpret_cast<const f16x8 *>(p_ry + c * 8);
+                    const f16x8 yv = *reinterpret_cast<const f16x8 *>(p_my + c * 8);
+                    f16x8 xs;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        xs[e] = (f16)((float)o[e] * (float)rv[e]);
+                        ps0 += (float)xs[e];
+                        ps1 += (float)o[e] * (float)yv[e];
+                        ps2 += (float)o[e];
+                    }
+                    *reinterpret_cast<f16x8 *>(p_xs + ro + c * 8) = xs;
+                }
             }
         }
+    }
+    if (NMIX == 1 && p_xs) {
+        block_sum3(ps0, ps1, ps2, red);
+        if (threadIdx.x == 0) fz.out_S[row * 3 + 0] = ps0, fz.out_S[row * 3 + 1] = ps1, fz.out_S[row * 3 + 2] = ps2;
     }
 }
 
@@ -322,6 +376,20 @@ extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, c
                                 const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
                                 const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
                                 const float *delta_partials, int delta_splits, void *stream) {
+    return rwkv7_add_ln_mix_mm8(B, T, C, n_mix, x, delta, x_out, ln_w, ln_b, eps, prev_in, prev_out, mix, out, out_stride, slot_idx,
+                                delta_partials, delta_splits, nullptr, stream);
+}
+
+extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
+                                    const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
+                                    const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
+                                    const float *delta_partials, int delta_splits, const chirrup_mm8_fuse *fuse, void *stream) {
+    chirrup_mm8_fuse q{};
+    if (fuse) q = *fuse;
+    if (q.in_S && (!delta_partials || !q.in_rx || !q.in_mx)) return CHIRRUP_E_NULL;
+    if (q.in_S && q.in_S_parts <= 0) q.in_S_parts = 1;
+    if (q.out_xs && (n_mix != 1 || !q.out_ry || !q.out_my || !q.out_S)) return q.out_xs && n_mix != 1 ? CHIRRUP_E_UNSUPPORTED : CHIRRUP_E_NULL;
+    if (mis16(q.in_rx) || mis16(q.in_mx) || mis16(q.out_ry) || mis16(q.out_my) || mis16(q.out_xs)) return CHIRRUP_E_ALIGN;
     if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
     if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;
     if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
@@ -339,7 +407,7 @@ extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, c
     const dim3 grid((unsigned)(B * T)), block(kLnThreads);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
              (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx, delta_partials, \
-             delta_splits, (int64_t)B * T * C
+             delta_splits, (int64_t)B * T * C, q
     if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
     else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
     else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);

@@ -58,16 +58,19 @@ constexpr int kTileRows = 128;   // rows of one tile image (skinny_tile_weight):
 
 enum { EPI_F16 = 0, EPI_PARTIAL = 1 };
 
-// two uint8 -> two binary16, exact: bytes b0,b1 -> halves 0x6400|b = 1024 + b, minus 1024
+// two uint8 -> two binary16 values 1024 + b (exact): bytes b0,b1 -> halves 0x6400|b.  ONE v_perm per pair and no
+// subtraction: the matrix cores multiply by (1024 + q) and the constant is taken out again with the other rank-1 terms of
+// the mm8 split form, core = sum_k xs*(1024 + q) - 1024*S0 (kU8Offset below; every product xs*(1024+q) is exact in
+// binary32, the sums carry 3 more bits of magnitude than without the offset -- ~1e-5 relative on the result, far inside
+// the binary16 output rounding).
+constexpr float kU8Offset = 1024.f;
 __device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
     // v_perm_b32: selector bytes pick from {src0 (hi dword), src1 (lo dword)}; 0x64 bytes come from a constant
     const uint32_t magic = 0x64646464u;
     uint32_t r;
-    if (sel_lo)  r = __builtin_amdgcn_perm(magic, packed, 0x04010400u);   // [b1,0x64 | b0,0x64] -> halves (b0),(b1)
+    if (sel_lo)  r = __builtin_amdgcn_perm(magic, packed, 0x04010400u);   // [b1,0x64 | b0,0x64] -> halves (1024+b0),(1024+b1)
     else         r = __builtin_amdgcn_perm(magic, packed, 0x04030402u);   // bytes 2,3
-    f16x2 v = __builtin_bit_cast(f16x2, r);
-    const f16x2 off = {(f16)1024.f, (f16)1024.f};
-    return v - off;
+    return __builtin_bit_cast(f16x2, r);
 }
 
 // Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
@@ -482,7 +485,8 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
 
 // Sum the split-K partials and apply the epilogue.
 //   mode 0: y = sum (+ bias[n]);  mode 1: y = relu(sum (+bias))^2;
-//   mode 2 (mm8): y = rx[n]*(sum + 0.5*S[m][0]) + S[m][1] + mx[n]*S[m][2]      (benchmark.py:167-179)
+//   mode 2 (mm8): y = rx[n]*(sum - 1024*S[m][0] + 0.5*S[m][0]) + S[m][1] + mx[n]*S[m][2]      (benchmark.py:167-179; the
+//                 u8 kernels multiply by 1024 + q, see cvt_u8x2)
 //   mode 3: mm8 then relu^2
 //   mode 4 + p: the RWKV-7 LoRA hidden planes (v, w, a, g), first problem = plane p: tanh on w, sigmoid on g
 //               (rwkv7.py:626, :630), applied to the binary16-rounded sum like the reference's separate op
@@ -513,12 +517,14 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const i
     const int m = (int)(gi / (N_ / 4)), n = (int)(gi % (N_ / 4)) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N_ + n);
-    f16x4 o;
+    f16x4 o, rxv = {}, mxv = {}, bv = {};
+    if (mm8) rxv = *reinterpret_cast<const f16x4 *>(rx + n), mxv = *reinterpret_cast<const f16x4 *>(mx + n);
+    else if (bias) bv = *reinterpret_cast<const f16x4 *>(bias + n);
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         float v = s[e];
-        if (mm8) v = (float)rx[n + e] * (v + 0.5f * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mx[n + e] * S[m * 3 + 2];
-        else if (bias) v += (float)bias[n + e];
+        if (mm8) v = (float)rxv[e] * (v - (kU8Offset - 0.5f) * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mxv[e] * S[m * 3 + 2];
+        else if (bias) v += (float)bv[e];
         if (act == 1) {
             v = (float)(f16)v;                       // relu(fp16(y))**2, rwkv7.py:678
             v = v > 0.f ? v * v : 0.f;
@@ -566,6 +572,73 @@ __global__ __launch_bounds__(256) void mm8_prep_kernel(const int K, const f16 *_
     }
     __syncthreads();
     if (threadIdx.x < 3) S[m * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// mm8 between two GEMMs: y = rx*(sum of core partials - 1023.5*S0) + S1 + mx*S2 (the rank-1 corrections of benchmark.py:
+// 174-179 for kernels that multiply by 1024 + q), optionally relu(fp16(y))^2 (rwkv7.py:678), written to Y if given -- and, if
+// the consumer is another mm8 product, its activation prologue on the fly (xs2 = fp16(y*ry2); S2 = {sum xs2, sum y*my2,
+// sum y}, mm8_prep_kernel's arithmetic), so that neither the reduce nor the next prologue is its own launch.
+// Grid (row, part): a 256-lane workgroup covers 1024 columns of one row, one 16-B load per split and lane; the row sums
+// come out as `parts` = ceil(N / 1024) partial sums per row, S2[row][part][3], which the consumers add up in part order
+// (rwkv7_add_ln_mix_mm8: in_S_parts; this kernel: S_parts) -- deterministic, no atomics.
+constexpr int kRowPart = 1024;
+__global__ __launch_bounds__(256) void mm8_reduce_rows_kernel(const int N, const int splits, const int64_t split_stride,
+                                                               const float *__restrict__ part, const f16 *__restrict__ rx,
+                                                               const f16 *__restrict__ mx, const float *__restrict__ S, const int S_parts,
+                                                               const int act, f16 *__restrict__ Y, const int ldy,
+                                                               const f16 *__restrict__ ry2, const f16 *__restrict__ my2,
+                                                               f16 *__restrict__ xs2, float *__restrict__ S2) {
+    __shared__ float red[3][4], ssum[3];
+    const int m = blockIdx.x, n = blockIdx.y * kRowPart + threadIdx.x * 4;
+    if (threadIdx.x < 3) {
+        float t = 0.f;
+        for (int p = 0; p < S_parts; p++) t += S[(m * S_parts + p) * 3 + threadIdx.x];
+        ssum[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const float s0 = ssum[0], s1 = ssum[1], s2 = ssum[2];
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    if (n < N) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < splits; k++)
+            v += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(part + k * split_stride + (int64_t)m * N + n));
+        const f16x4 rxv = *reinterpret_cast<const f16x4 *>(rx + n), mxv = *reinterpret_cast<const f16x4 *>(mx + n);
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float y = (float)rxv[e] * (v[e] - (kU8Offset - 0.5f) * s0) + s1 + (float)mxv[e] * s2;
+            if (act) {
+                y = (float)(f16)y;
+                y = y > 0.f ? y * y : 0.f;
+            }
+            o[e] = (f16)y;
+        }
+        if (Y) *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+        if (xs2) {
+            const f16x4 ryv = *reinterpret_cast<const f16x4 *>(ry2 + n), myv = *reinterpret_cast<const f16x4 *>(my2 + n);
+            f16x4 xs;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                xs[e] = (f16)((float)o[e] * (float)ryv[e]);
+                t0 += (float)xs[e];
+                t1 += (float)o[e] * (float)myv[e];
+                t2 += (float)o[e];
+            }
+            *reinterpret_cast<f16x4 *>(xs2 + (int64_t)m * N + n) = xs;
+        }
+    }
+    if (!xs2) return;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        t0 += __shfl_xor(t0, o, 64);
+        t1 += __shfl_xor(t1, o, 64);
+        t2 += __shfl_xor(t2, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = t0, red[1][threadIdx.x >> 6] = t1, red[2][threadIdx.x >> 6] = t2;
+    __syncthreads();
+    if (threadIdx.x < 3)
+        S2[(m * gridDim.y + blockIdx.y) * 3 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
 // Output columns per workgroup.  256 wherever there are enough columns to fill the chip with 256-wide tiles at a sane
@@ -725,7 +798,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     if (act < 0 || act > 1) return CHIRRUP_E_UNSUPPORTED;
     if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
-    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7)) return CHIRRUP_E_ALIGN;
+    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7) || (reinterpret_cast<uintptr_t>(bias) & 7)) return CHIRRUP_E_ALIGN;
     const int bn = choose_bn(N);
     const int s = pick_splits(bn, N, K, splits);
     const bool partial = s > 1;                        // unsplit: bias and relu^2 run in the kernel's own epilogue
@@ -775,7 +848,8 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
         (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
         return CHIRRUP_E_SHAPE;
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
-    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7)) return CHIRRUP_E_ALIGN;
+    if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7) || (reinterpret_cast<uintptr_t>(bias) & 7) || (bias_bs & 3))
+        return CHIRRUP_E_ALIGN;
     const int bn = choose_bn(N);
     const int s = pick_splits(bn, N, K, splits, Z);
     const bool partial = s > 1 || act != 0;
@@ -855,7 +929,7 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
         const chirrup_gemm_problem &q = problems[i];
         if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
         if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
-        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7)) return CHIRRUP_E_ALIGN;
+        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7) || (reinterpret_cast<uintptr_t>(q.bias) & 7)) return CHIRRUP_E_ALIGN;
         gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y);
         gt.bias[i] = static_cast<const f16 *>(q.bias), gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act;
         if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
@@ -919,6 +993,7 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         return CHIRRUP_E_SHAPE;
     if (!x || !wT || !mx || !rx || !my || !ry || !y || !workspace) return CHIRRUP_E_NULL;
     if (mis16(x) || mis16(wT) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return CHIRRUP_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(mx) & 7) || (reinterpret_cast<uintptr_t>(rx) & 7) || mis16(my) || mis16(ry)) return CHIRRUP_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int bnc = choose_bn(M_out);
     const int s = pick_splits(bnc, M_out, N_in, splits);
@@ -952,4 +1027,47 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         if (rc) return rc;
     }
     return 0;
+}
+
+// The matrix product of mm8t_seq alone, for callers that fuse its prologue and its reduce into the neighbouring kernels
+// (rwkv7_add_ln_mix_mm8, mm8_reduce_rows): xs = the prologue's output [B][N_in] binary16 (B <= 256), partials receive the
+// fp32 core sums [splits][B][M_out].  Returns the split count used (> 0) or a negative error like skinny_gemm_f16_partial.
+extern "C" int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride,
+                                 int w_tiled, int splits, float *partials, void *stream) {
+    if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || xs_stride < N_in || w_stride < N_in ||
+        (xs_stride & 7) || (w_stride & 15))
+        return CHIRRUP_E_SHAPE;
+    if (!xs || !wT || !partials) return CHIRRUP_E_NULL;
+    if (mis16(xs) || mis16(wT) || mis16(partials)) return CHIRRUP_E_ALIGN;
+    const int bn = choose_bn(M_out);
+    const int s = pick_splits(bn, M_out, N_in, splits);
+    const dim3 grid((M_out + bn - 1) / bn, s);
+    BatchStrides bs{};
+    bs.tiled = w_tiled ? 1 : 0;
+    const int rc = launch_gemm<true, EPI_PARTIAL>(bn, (B + 15) / 16, grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
+                                                  static_cast<const f16 *>(xs), xs_stride, wT, w_stride, nullptr, M_out, nullptr, partials, bs);
+    return rc ? -1000 - rc : s;
+}
+
+// Row-wise reduce of an mm8 product's partials with its rank-1 corrections (+ relu^2 when act = 1), writing y (may be
+// NULL) and/or the activation prologue (xs2, S2 for scales ry2, my2) of the NEXT mm8 product.  M_out % 4 == 0.
+// S is given as S_parts partial sums per row ([B][S_parts][3]); S2 is written as mm8_row_parts(M_out) partial sums per row.
+extern "C" int mm8_row_parts(int M_out) { return M_out > 0 ? (M_out + kRowPart - 1) / kRowPart : 0; }
+
+extern "C" int mm8_reduce_rows(int B, int M_out, int splits, const float *partials, const void *rx, const void *mx, const float *S,
+                               int S_parts, int act, void *y, int y_stride, const void *ry2, const void *my2, void *xs2, float *S2,
+                               void *stream) {
+    if (B <= 0 || M_out <= 0 || (M_out & 3) || splits <= 0 || S_parts <= 0 || (y && (y_stride < M_out || (y_stride & 3)))) return CHIRRUP_E_SHAPE;
+    if (!partials || !rx || !mx || !S || (!y && !xs2)) return CHIRRUP_E_NULL;
+    if (xs2 && (!ry2 || !my2 || !S2)) return CHIRRUP_E_NULL;
+    if (mis16(partials) || (reinterpret_cast<uintptr_t>(y) & 7) || (reinterpret_cast<uintptr_t>(xs2) & 7) ||
+        (reinterpret_cast<uintptr_t>(rx) & 7) || (reinterpret_cast<uintptr_t>(mx) & 7) || (reinterpret_cast<uintptr_t>(ry2) & 7) ||
+        (reinterpret_cast<uintptr_t>(my2) & 7))
+        return CHIRRUP_E_ALIGN;
+    hipLaunchKernelGGL(mm8_reduce_rows_kernel, dim3(B, mm8_row_parts(M_out)), dim3(256), 0, static_cast<hipStream_t>(stream), M_out, splits,
+                       (int64_t)B * M_out, partials, static_cast<const f16 *>(rx), static_cast<const f16 *>(mx), S, S_parts, act,
+                       static_cast<f16 *>(y), y_stride, static_cast<const f16 *>(ry2), static_cast<const f16 *>(my2),
+                       static_cast<f16 *>(xs2), S2);
+    return (int)hipGetLastError();
 }

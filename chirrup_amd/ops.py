@@ -226,10 +226,18 @@ def _chk16(name, t, numel=None):
         raise _lib.ChirrupAmdError(f"{name}: expected {numel} elements, got {t.numel()}")
 
 
+class _Mm8Fuse(ctypes.Structure):
+    """chirrup_mm8_fuse of include/chirrup_amd.h"""
+    _fields_ = [("in_rx", ctypes.c_void_p), ("in_mx", ctypes.c_void_p), ("in_S", ctypes.c_void_p), ("out_ry", ctypes.c_void_p),
+                ("out_my", ctypes.c_void_p), ("out_xs", ctypes.c_void_p), ("out_S", ctypes.c_void_p), ("in_S_parts", ctypes.c_int)]
+
+
 def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out,
-               slot_idx=None, delta_partials=None) -> None:
+               slot_idx=None, delta_partials=None, mm8_in=None, mm8_out=None) -> None:
     """x_new = x (+delta) -> x_out; cur = LN(x_new); out[m] = cur + (shifted - cur) * mix[m]
-    (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h."""
+    (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h.
+    mm8_in = (rx [C], mx [C], S fp32 [B*T,3] or [B*T,parts,3]): delta_partials are the core sums of an mm8 product, corrected here;
+    mm8_out = (ry [C], my [C], xs fp16 [B*T,C], S fp32 [B*T,3]): also write the mm8 prologue of out (n_mix == 1)."""
     n_mix = 0 if mix is None else mix.shape[0]
     for name, t in (("x", x), ("delta", delta), ("x_out", x_out)):
         _chk16(name, t, B * T * C)
@@ -250,9 +258,25 @@ def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, 
                 or delta_partials.numel() % (B * T * C):
             raise _lib.ChirrupAmdError("delta_partials: expected contiguous fp32 [splits, B*T, C] and delta=None")
         dsplits = delta_partials.numel() // (B * T * C)
-    rc = _lib.load().rwkv7_add_ln_mix(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
-                                      _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _ptr(slot_idx),
-                                      _ptr(delta_partials), dsplits, _stream())
+    fuse = None
+    if mm8_in is not None or mm8_out is not None:
+        fz = _Mm8Fuse()
+        if mm8_in is not None:
+            rx, mx, S = mm8_in
+            _chk16("mm8_in rx", rx, C), _chk16("mm8_in mx", mx, C)
+            _chk(S, "mm8_in S", torch.float32)
+            if S.numel() % (B * T * 3):
+                raise _lib.ChirrupAmdError("mm8_in S: expected fp32 [B*T, parts, 3]")
+            fz.in_rx, fz.in_mx, fz.in_S, fz.in_S_parts = rx.data_ptr(), mx.data_ptr(), S.data_ptr(), S.numel() // (B * T * 3)
+        if mm8_out is not None:
+            ry, my, xs, S = mm8_out
+            _chk16("mm8_out ry", ry, C), _chk16("mm8_out my", my, C), _chk16("mm8_out xs", xs, B * T * C)
+            _chk(S, "mm8_out S", torch.float32, (B * T, 3))
+            fz.out_ry, fz.out_my, fz.out_xs, fz.out_S = ry.data_ptr(), my.data_ptr(), xs.data_ptr(), S.data_ptr()
+        fuse = ctypes.addressof(fz)
+    rc = _lib.load().rwkv7_add_ln_mix_mm8(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
+                                          _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _ptr(slot_idx),
+                                          _ptr(delta_partials), dsplits, fuse, _stream())
     _lib.check(rc, "rwkv7_add_ln_mix")
 
 
@@ -517,6 +541,52 @@ def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None, 
                     my.data_ptr(), ry.data_ptr(), out.data_ptr(), out.stride(0), act, splits, base, _stream())
     _lib.check(rc, "mm8t_seq")
     return out
+
+
+def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = False):
+    """The matrix product of mm8t_linear alone: xs [B<=256, N_in] fp16 (an mm8 prologue's output) against wT; fp32 core sums
+    into `partials`, returned as the view [splits_used, B, M_out] (include/chirrup_amd.h: mm8t_gemm_partial)."""
+    B, N = xs.shape
+    if not xs.is_cuda or xs.dtype != torch.float16 or xs.stride(1) != 1:
+        raise _lib.ChirrupAmdError("xs: expected GPU fp16 with unit inner stride")
+    if not wT.is_cuda or wT.dtype != torch.uint8 or wT.numel() != M_out * N:
+        raise _lib.ChirrupAmdError("wT: expected GPU uint8 with M_out*N_in elements")
+    if partials.dtype != torch.float32 or not partials.is_contiguous():
+        raise _lib.ChirrupAmdError("partials: expected contiguous fp32")
+    s_used = gemm_splits(M_out, N, 1, splits)
+    if partials.numel() < s_used * B * M_out:
+        raise _lib.ChirrupAmdError("partials buffer too small")
+    rc = _lib.load().mm8t_gemm_partial(B, N, M_out, xs.data_ptr(), xs.stride(0), wT.data_ptr(), N, int(tiled), splits,
+                                       partials.data_ptr(), _stream())
+    if rc <= 0:
+        raise _lib.ChirrupAmdError(f"mm8t_gemm_partial: {rc}")
+    return partials.view(-1)[: rc * B * M_out].view(rc, B, M_out)
+
+
+def mm8_row_parts(M: int) -> int:
+    """Partial row sums per row that mm8_reduce_rows writes for an [.., M] product."""
+    return _lib.load().mm8_row_parts(M)
+
+
+def mm8_reduce_rows(parts, rx, mx, S, act: int = 0, y=None, nxt=None) -> None:
+    """Row-wise reduce of mm8 core partials [splits, B, M] with the rank-1 corrections (+ relu^2): writes y [B, M] if given
+    and, with nxt = (ry2, my2, xs2 [B, M], S2 [B, mm8_row_parts(M), 3]), the prologue of the next mm8 product
+    (include/chirrup_amd.h).  S: fp32 [B, 3] or [B, parts, 3]."""
+    splits, B, M = parts.shape
+    _chk16("rx", rx, M), _chk16("mx", mx, M)
+    _chk(S, "S", torch.float32)
+    if S.numel() % (B * 3):
+        raise _lib.ChirrupAmdError("S: expected fp32 [B, parts, 3]")
+    ry2 = my2 = xs2 = S2 = None
+    if nxt is not None:
+        ry2, my2, xs2, S2 = nxt
+        _chk16("ry2", ry2, M), _chk16("my2", my2, M), _chk16("xs2", xs2, B * M)
+        _chk(S2, "S2", torch.float32, (B, mm8_row_parts(M), 3))
+    if y is not None:
+        _chk16("y", y, B * M)
+    rc = _lib.load().mm8_reduce_rows(B, M, splits, parts.data_ptr(), rx.data_ptr(), mx.data_ptr(), S.data_ptr(), S.numel() // (B * 3),
+                                     act, _ptr(y), M, _ptr(ry2), _ptr(my2), _ptr(xs2), _ptr(S2), _stream())
+    _lib.check(rc, "mm8_reduce_rows")
 
 
 def sample_topp(logits, rows, temperature, top_p, top_k, uniform, ids, slot_idx=None) -> None:

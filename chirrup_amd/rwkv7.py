@@ -422,6 +422,17 @@ class RWKV_x070:
         pbuf_o = (torch.empty((ops.gemm_splits(C, C, 1, gs["att_out"]), rows, C), dtype=torch.float32, device=dev)
                   if (hw and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
 
+        # mm8 FFN in the decode regime: prologue / reduce launches of the two u8 products folded into the LN kernels and one
+        # row-reduce kernel between them (same arithmetic as ops.mm8t_linear)
+        q8 = hw and self.ffn_dtype == torch.int8 and T == 1
+        dq = None                         # (rx, mx, S) of the mm8 product whose core partials `dparts` holds
+        if q8:
+            f32 = dict(dtype=torch.float32, device=dev)
+            xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
+            xs_v, S_v = new(rows, 4 * C), torch.empty((rows, ops.mm8_row_parts(4 * C), 3), **f32)
+            pbuf_k = torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), rows, 4 * C), **f32)
+            pbuf = torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), **f32)
+
         def commit_carry(prev):
             if slot_idx is None:
                 prev.copy_(carry)
@@ -436,7 +447,7 @@ class RWKV_x070:
             prev = s0[i][0]
             upd = delta is not None or dparts is not None
             ops.add_ln_mix(B, T, C, x, delta, (x if T == 1 else x_alt) if upd else None, lw.ln1_w, lw.ln1_b,
-                           1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts)
+                           1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts, mm8_in=dq)
             if T > 1:
                 if upd:
                     x, x_alt = x_alt, x
@@ -498,18 +509,24 @@ class RWKV_x070:
                 ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
+            q8_out = (lw.f_K8.ry, lw.f_K8.my, xs_k, S_k) if q8 else None
             if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
                 aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, gs["att_out"], pbuf_o)   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
-                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts)
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts, mm8_out=q8_out)
             else:
                 att = F.linear(o_in, lw.O)
                 ops.add_ln_mix(B, T, C, x, att, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
-                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx)
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, mm8_out=q8_out)
             if T > 1:
                 x, x_alt = x_alt, x
                 commit_carry(prev)
-            if self.ffn_dtype == torch.int8:        # mm8 on the matrix cores, relu^2 fused into the epilogue
+            if q8:
+                kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled)
+                ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))
+                dparts, delta = ops.mm8t_gemm_partial(xs_v, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled), None
+                dq = (lw.f_V8.rx, lw.f_V8.mx, S_v)
+            elif self.ffn_dtype == torch.int8:      # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)
                 delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)
             else:
@@ -535,7 +552,7 @@ class RWKV_x070:
             rows_out = (B, T)
         xo = new(rows_out[0], rows_out[1], C)
         ops.add_ln_mix(rows_out[0], rows_out[1], C, x, delta, None, z["ln_out.weight"], z["ln_out.bias"], 1e-5, None, None,
-                       None, xo, delta_partials=dparts)
+                       None, xo, delta_partials=dparts, mm8_in=dq)
         if not full_output:
             xo = xo.view(B, C)
         if slot_idx is not None:

@@ -130,6 +130,27 @@ int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *
                      const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
                      const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
                      const float *delta_partials, int delta_splits, void *stream);
+/* The same kernel next to mm8 (w8a16) GEMMs, whose split form (scripts/test_mm8/benchmark.py:167-179) has an activation
+ * prologue (xs = fp16(x*ry), S = {sum xs, sum x*my, sum x} per row) and rank-1 corrections after the matrix product:
+ *   in_*  : delta_partials hold the CORE sums of an mm8 product (mm8t_gemm_partial) with output scales in_rx, in_mx [C] and
+ *           the row sums in_S [B*T][3] of ITS prologue: delta = fp16(rx*(sum - 1023.5*S0) + S1 + mx*S2) is formed here (the
+ *           u8 kernels multiply by 1024 + q, so the core sums carry 1024*S0, removed with the +0.5*S0 term) -- the
+ *           product's reduce launch folded into this kernel (as delta_partials does for the binary16 GEMMs);
+ *   out_* : (n_mix == 1 only) besides out, write the prologue of the mm8 product that consumes out: out_xs [B][T][C] and
+ *           out_S [B*T][3] for input scales out_ry, out_my [C] -- that product's prologue launch folded in.
+ * Either half may be all-NULL; fuse == NULL is rwkv7_add_ln_mix. */
+typedef struct {
+    const void *in_rx, *in_mx;   /* binary16 [C] */
+    const float *in_S;           /* [B*T][in_S_parts][3]: the row sums as in_S_parts partial sums each (added up here) */
+    const void *out_ry, *out_my; /* binary16 [C] */
+    void *out_xs;                /* binary16 [B][T][C] */
+    float *out_S;                /* [B*T][3] */
+    int in_S_parts;              /* 0 or 1: one sum per row; mm8_reduce_rows writes mm8_row_parts(C) of them */
+} chirrup_mm8_fuse;
+int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
+                         const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
+                         const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
+                         const float *delta_partials, int delta_splits, const chirrup_mm8_fuse *fuse, void *stream);
 
 /* rwkv7.py:629-637: a = sigmoid(a_pre); kk = normalize(k*k_k) per 64-channel head;
  * k <- k*(1+(a-1)*k_a) in place; neg_kk = -kk; kka = kk*a; and, when v_first != NULL (layer > 0),
@@ -267,6 +288,25 @@ int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const f
 int rwkv7_sample_topp(int n_rows, int V, const void *logits, const int32_t *rows, const void *temperature,
                       const void *top_p, const int32_t *top_k, const int32_t *slot_idx, const float *uniform,
                       int32_t *ids, void *stream);
+
+/*
+ * The pieces of mm8t_seq for a decode step that folds the mm8 prologue / reduce launches into the neighbouring kernels
+ * (chirrup_amd/rwkv7.py, ffn_dtype = int8): LN kernel (prologue of ffn.key, rwkv7_add_ln_mix_mm8) -> mm8t_gemm_partial ->
+ * mm8_reduce_rows (corrections + relu^2 of ffn.key AND the prologue of ffn.value) -> mm8t_gemm_partial -> next LN kernel
+ * (corrections of ffn.value).  Same arithmetic and rounding points as mm8t_seq.
+ * mm8t_gemm_partial: core sums of xs [B][N_in] (B <= 256) against wT into partials [splits][B][M_out]; returns the split
+ *   count used (> 0) or a negative error.
+ * mm8_reduce_rows: y = act(rx*(sum partials - 1023.5*S[.][0]) + S[.][1] + mx*S[.][2]) (y may be NULL), and when xs2 != NULL the
+ *   prologue of the next product: xs2 = fp16(y*ry2), S2 = {sum xs2, sum y*my2, sum y} per row.  Row sums travel as partial
+ *   sums: S is [B][S_parts][3], S2 is written as [B][mm8_row_parts(M_out)][3] (one part per 1024 columns), to be added in
+ *   part order by the consumer (rwkv7_add_ln_mix_mm8: in_S_parts; this function: S_parts).
+ */
+int mm8_row_parts(int M_out);
+int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride,
+                      int w_tiled, int splits, float *partials, void *stream);
+int mm8_reduce_rows(int B, int M_out, int splits, const float *partials, const void *rx, const void *mx, const float *S,
+                    int S_parts, int act, void *y, int y_stride, const void *ry2, const void *my2, void *xs2, float *S2,
+                    void *stream);
 
 #ifdef __cplusplus
 }

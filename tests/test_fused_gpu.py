@@ -171,3 +171,52 @@ def test_fused_tmix_core_equals_three_kernel_path(oracle, B, T, C, layer0):
     assert (bits(s_a) != bits(s_b)).mean() < 0.02
     assert float(np.abs(s_a.astype(F32) - s_b.astype(F32)).max()) <= 2e-3 * scale
     assert_close_ulps(out1.cpu().numpy(), out3.cpu().numpy(), 2, 0.05, "out", atol=4e-3 * max(1.0, float(out3.abs().max())))
+
+
+@pytest.mark.parametrize("rows,C", [(5, 128), (200, 1024)])
+def test_mm8_chain_folded_into_neighbouring_kernels_equals_mm8t_linear(rows, C):
+    """Decode-regime mm8 FFN: the activation prologue of ffn.key written by the LN kernel, corrections + relu^2 of ffn.key
+    and the prologue of ffn.value in ONE row kernel, corrections of ffn.value in the next LN kernel -- the same operations
+    and rounding points as the stand-alone mm8t_linear calls (bit-identical up to the order of the binary32 row sums)."""
+    from chirrup_amd import ops
+    from chirrup_amd.quant import quantize_linear
+
+    torch.manual_seed(rows + C)
+    dev = "cuda"
+    K8 = quantize_linear((torch.randn(4 * C, C, device=dev) / C ** 0.5).half())
+    V8 = quantize_linear((torch.randn(C, 4 * C, device=dev) / (4 * C) ** 0.5).half())
+    x = torch.randn(rows, 1, C, device=dev).half()
+    att = (torch.randn(rows, 1, C, device=dev) * 0.3).half()
+    w, b = (1 + 0.1 * torch.randn(C, device=dev)).half(), (0.1 * torch.randn(C, device=dev)).half()
+    prev, mix = torch.randn(rows, C, device=dev).half(), torch.rand(1, C, device=dev).half()
+    # reference: separate launches
+    x_ref, prev_ref = x.clone(), prev.clone()
+    kin_ref = torch.empty(1, rows, 1, C, dtype=torch.float16, device=dev)
+    ops.add_ln_mix(rows, 1, C, x_ref, att, x_ref, w, b, 1e-5, prev_ref, prev_ref, mix, kin_ref)
+    kf_ref = ops.mm8t_linear(kin_ref[0].view(rows, C), *K8, act=1)
+    d_ref = ops.mm8t_linear(kf_ref, *V8)
+    x2_ref, out_ref = x_ref.clone(), torch.empty(1, rows, 1, C, dtype=torch.float16, device=dev)
+    ops.add_ln_mix(rows, 1, C, x2_ref, d_ref.view(rows, 1, C), x2_ref, w, b, 1e-5, None, None, None, out_ref)
+    # fused chain
+    f32 = dict(dtype=torch.float32, device=dev)
+    x_f, prev_f = x.clone(), prev.clone()
+    kin = torch.empty(1, rows, 1, C, dtype=torch.float16, device=dev)
+    xs_k, S_k = torch.empty(rows, C, dtype=torch.float16, device=dev), torch.empty(rows, 3, **f32)
+    xs_v, S_v = torch.empty(rows, 4 * C, dtype=torch.float16, device=dev), torch.empty(rows, ops.mm8_row_parts(4 * C), 3, **f32)
+    ops.add_ln_mix(rows, 1, C, x_f, att, x_f, w, b, 1e-5, prev_f, prev_f, mix, kin, mm8_out=(K8.ry, K8.my, xs_k, S_k))
+    assert torch.equal(kin, kin_ref) and torch.equal(prev_f, prev_ref)
+    pk = torch.empty(16, rows, 4 * C, **f32)
+    kparts = ops.mm8t_gemm_partial(xs_k, K8.qT, 4 * C, 0, pk)
+    kf = torch.empty(rows, 4 * C, dtype=torch.float16, device=dev)
+    ops.mm8_reduce_rows(kparts, K8.rx, K8.mx, S_k, act=1, y=kf, nxt=(V8.ry, V8.my, xs_v, S_v))
+    assert torch.equal(kf, kf_ref)
+    pv = torch.empty(16, rows, C, **f32)
+    vparts = ops.mm8t_gemm_partial(xs_v, V8.qT, C, 0, pv)
+    out = torch.empty(1, rows, 1, C, dtype=torch.float16, device=dev)
+    ops.add_ln_mix(rows, 1, C, x_f, None, x_f, w, b, 1e-5, None, None, None, out, delta_partials=vparts.view(-1, rows, C),
+                   mm8_in=(V8.rx, V8.mx, S_v))
+    # the row sums S of ffn.value's prologue are binary32 sums in another order here (1024-lane row kernel vs the
+    # stand-alone prologue kernel): a delta may move by one binary16 ulp on a few elements, never more
+    dx = (x_f.float() - x2_ref.float()).abs()
+    assert float(dx.max()) <= 4e-3 and float((dx > 0).float().mean()) < 0.10      # (the 1024*S0 term of the u8 offset makes delta that sensitive to the order of the S0 sum)
+    assert float((out.float() - out_ref.float()).abs().max()) <= 8e-3
