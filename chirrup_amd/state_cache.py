@@ -16,16 +16,51 @@ Two parts:
 * ``HbmStateArena`` -- where the states live on an MI355X.  The reference keeps ``[L,2,1,C]``, ``[L,1,H,64,64]``,
   ``[1]`` CPU tensors per entry (worker.py:426-430) and pays two PCIe transfers of 17-33 MB per hit.  With 288 GB
   of HBM the cache is a preallocated, index-addressed pool on the device: ``capacity`` rows of
-  ``[L,2,C] + [L,H,64,64] + [1]``; caching a prefix is one device-to-device copy into a free row, a hit hands out
-  a device clone of the row (so an eviction can never pull a state from under a request that is still queued),
-  eviction just returns the row to the free list.  4096 rows of a 13.3B state (33 MB) are 135 GB.
+  ``[L,2,C] + [L,H,64,64] + [1]``.  States move between the worker's slot table and the arena by ONE device-to-device
+  copy each way: the worker exports a prefix straight into a free row (``export_slot``), a hit hands the request an
+  ``ArenaRef`` -- a pinned handle on the row, no data -- and ``Worker._install`` copies the row straight into the slot
+  (``ArenaRef.install_into``) and unpins it.  A row that is evicted while a hit on it is still queued is only returned
+  to the free list when the last pin is gone.  4096 rows of a 13.3B state (33 MB) are 135 GB.
   ``SimpleStateCache(max_size, arena=HbmStateArena(...))`` stores its states there.
 """
 import asyncio
+import threading
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+
+
+class ArenaRef:
+    """A pinned handle on one arena row: what a prefix-cache hit hands to the request (``Task.state``).  The row cannot be
+    reused until ``release()`` (``Worker._install`` calls it after its copy is enqueued; dropping the handle releases too)."""
+    __slots__ = ("arena", "row", "_live")
+
+    def __init__(self, arena: "HbmStateArena", row: int):
+        self.arena, self.row, self._live = arena, row, True
+
+    def install_into(self, pool: Sequence[torch.Tensor], slot: int) -> None:
+        """One strided device-to-device copy per state tensor: arena row -> slot `slot` of the worker's tables
+        [L,2,n,C], [L,n,H,64,64], [n] (works across devices: a peer copy over xGMI)."""
+        a = self.arena
+        pool[0][:, :, slot, :].copy_(a.shift[self.row], non_blocking=True)
+        pool[1][:, slot].copy_(a.wkv[self.row], non_blocking=True)
+        pool[2][slot: slot + 1].copy_(a.elapsed[self.row: self.row + 1], non_blocking=True)
+
+    def tensors(self) -> List[torch.Tensor]:
+        """Copies in the reference's exported layout [L,2,1,C], [L,1,H,64,64], [1] (for consumers that want tensors)."""
+        return self.arena.get(self.row)
+
+    def release(self) -> None:
+        if self._live:
+            self._live = False
+            self.arena._unpin(self.row)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 class HbmStateArena:
@@ -40,6 +75,9 @@ class HbmStateArena:
         self.wkv = torch.empty((capacity, n_layer, H, head_size, head_size), dtype=dtype, device=device)  # state[1] rows
         self.elapsed = torch.zeros((capacity,), dtype=torch.int32, device=device)                       # state[2]
         self._free = list(range(capacity - 1, -1, -1))
+        self._pins = [0] * capacity
+        self._doomed = set()          # rows released by their owner while pinned: freed by the last unpin
+        self._lock = threading.Lock()  # the cache runs on the engine's thread, installs on the worker's
 
     @classmethod
     def for_model(cls, model, capacity: int):
@@ -54,25 +92,69 @@ class HbmStateArena:
     def free_rows(self) -> int:
         return len(self._free)
 
+    def _take_row(self) -> int:
+        with self._lock:
+            if not self._free:
+                raise RuntimeError("HbmStateArena is full (the cache's max_size must not exceed the arena's capacity)")
+            return self._free.pop()
+
     def put(self, state: Sequence[torch.Tensor]) -> int:
         """Copy one exported state ([L,2,1,C], [L,1,H,64,64], [1]; any device) into a free row; returns the row."""
-        if not self._free:
-            raise RuntimeError("HbmStateArena is full (the cache's max_size must not exceed the arena's capacity)")
         s0, s1, s2 = state
         if tuple(s0.shape) != (self.n_layer, 2, 1, self.n_embd) or s1.shape[0] != self.n_layer or s1.shape[1] != 1:
             raise ValueError(f"state shapes {tuple(s0.shape)}, {tuple(s1.shape)} do not match the arena")
-        row = self._free.pop()
+        row = self._take_row()
         self.shift[row].copy_(s0[:, :, 0, :], non_blocking=True)
         self.wkv[row].copy_(s1[:, 0], non_blocking=True)
         self.elapsed[row: row + 1].copy_(s2.reshape(1), non_blocking=True)
         return row
 
+    def export_slot(self, pool: Sequence[torch.Tensor], slot: int) -> "ArenaRef":
+        """Copy slot `slot` of a worker's state tables straight into a free row (one strided copy per tensor) and return a
+        handle on it -- what ``Worker._export_state`` sends with ("cache_prefill", ...) when it has an arena; hand it to
+        ``SimpleStateCache.cache`` (which takes the row over) or release it."""
+        if tuple(pool[0].shape[:2]) != (self.n_layer, 2) or pool[0].shape[3] != self.n_embd:
+            raise ValueError("state tables do not match the arena")
+        row = self._take_row()
+        self.shift[row].copy_(pool[0][:, :, slot, :], non_blocking=True)
+        self.wkv[row].copy_(pool[1][:, slot], non_blocking=True)
+        self.elapsed[row: row + 1].copy_(pool[2][slot: slot + 1], non_blocking=True)
+        with self._lock:
+            self._pins[row] += 1
+            self._doomed.add(row)           # nobody owns it yet: the row goes back when this handle is released ...
+        return ArenaRef(self, row)
+
+    def adopt(self, ref: "ArenaRef") -> int:
+        """... unless a cache adopts it (``SimpleStateCache.cache``): the row now lives until the cache releases it."""
+        with self._lock:
+            self._doomed.discard(ref.row)
+        ref.release()
+        return ref.row
+
+    def ref(self, row: int) -> "ArenaRef":
+        """A pinned handle on a cached row (a prefix-cache hit)."""
+        with self._lock:
+            self._pins[row] += 1
+        return ArenaRef(self, row)
+
+    def _unpin(self, row: int) -> None:
+        with self._lock:
+            self._pins[row] -= 1
+            if self._pins[row] == 0 and row in self._doomed:
+                self._doomed.discard(row)
+                self._free.append(row)
+
     def get(self, row: int) -> List[torch.Tensor]:
-        """A device copy of row ``row`` in the layout ``Task.state`` / ``Worker._install`` expect."""
+        """A device copy of row ``row`` in the layout the reference exports ([L,2,1,C], [L,1,H,64,64], [1])."""
         return [self.shift[row].unsqueeze(2).clone(), self.wkv[row].unsqueeze(1).clone(), self.elapsed[row: row + 1].clone()]
 
     def release(self, row: int) -> None:
-        self._free.append(row)
+        """The owner (the cache) gives the row up; it is reused once no hit holds it any more."""
+        with self._lock:
+            if self._pins[row] > 0:
+                self._doomed.add(row)
+            else:
+                self._free.append(row)
 
 
 class _ArenaRow:
@@ -120,7 +202,7 @@ class SimpleStateCache:
 
     def _materialise(self, stored):
         if isinstance(stored, _ArenaRow):
-            return self.arena.get(stored.row)
+            return self.arena.ref(stored.row)        # a pinned handle, no copy: Worker._install copies row -> slot once
         return stored
 
     def _drop_path(self, tokens: Tuple[int, ...]) -> None:
@@ -182,7 +264,16 @@ class SimpleStateCache:
             node = node.children.setdefault(tok, TrieNode())
             node.entries += 1
         node.state = True
-        self._lru[tokens] = _ArenaRow(self._put_after_eviction(state)) if self.arena is not None else state
+        if self.arena is not None and isinstance(state, ArenaRef) and state.arena is self.arena:
+            if len(self._lru) >= self.max_size:      # the state already sits in a row (Worker export): take the row over
+                old_key, old_state = self._lru.popitem(last=False)
+                self._drop_path(old_key)
+                self._discard_state(old_state)
+            self._lru[tokens] = _ArenaRow(self.arena.adopt(state))
+        else:
+            if isinstance(state, ArenaRef):
+                state = state.tensors()
+            self._lru[tokens] = _ArenaRow(self._put_after_eviction(state)) if self.arena is not None else state
         if self.arena is None and len(self._lru) > self.max_size:
             old_key, old_state = self._lru.popitem(last=False)
             self._drop_path(old_key)
@@ -190,8 +281,14 @@ class SimpleStateCache:
         return node if return_trie_node else None
 
     def _put_after_eviction(self, state) -> int:
-        """Arena-backed insert: make room first (the arena may be exactly max_size rows)."""
+        """Arena-backed insert: make room first (the arena may be exactly max_size rows).  A row whose prefix is evicted
+        while a hit on it is still queued stays occupied until that hit is installed, so an arena without spare rows can
+        be momentarily full: further least-recently-used prefixes are given up until a row is free."""
         if len(self._lru) >= self.max_size:
+            old_key, old_state = self._lru.popitem(last=False)
+            self._drop_path(old_key)
+            self._discard_state(old_state)
+        while self.arena.free_rows == 0 and self._lru:
             old_key, old_state = self._lru.popitem(last=False)
             self._drop_path(old_key)
             self._discard_state(old_state)
@@ -247,4 +344,4 @@ class SimpleStateCache:
         return None
 
 
-__all__ = ["SimpleStateCache", "HbmStateArena", "TrieNode"]
+__all__ = ["SimpleStateCache", "HbmStateArena", "ArenaRef", "TrieNode"]

@@ -82,7 +82,8 @@ def _empty_slot() -> dict:
 class Worker:
     def __init__(self, worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, task_queue: queue.Queue,
                  master_event_queue: queue.Queue, worker_event_queue: Optional[queue.Queue], batch_size: int = 32,
-                 model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None, run_ahead: bool = True):
+                 model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None, run_ahead: bool = True,
+                 state_arena=None):
         self.worker_id, self.gpu_id, self.model_config = worker_id, gpu_id, model_config
         self.task_queue, self.master_event_queue, self.worker_event_queue = task_queue, master_event_queue, worker_event_queue
         self.real_state_size = batch_size
@@ -97,6 +98,9 @@ class Worker:
         # 17-33 MB device-to-device copies instead of two PCIe transfers per cache hit); "cpu" = the
         # reference's behaviour (worker.py:427-429)
         self.state_cache_device = state_cache_device
+        # an HbmStateArena on this worker's device: prefix states are exported straight into a free arena row (one copy)
+        # and travel as ArenaRef handles; without it they are device clones (or host copies, state_cache_device="cpu")
+        self.state_arena = state_arena
         self.run_ahead = run_ahead
         self.on_fatal = None                          # callable(worker, exception), set by the engine
         self._inflight = None                         # the forward whose sampled ids the host has not handled yet
@@ -184,6 +188,8 @@ class Worker:
     def _export_state(self, slot: int):
         """[state0[:, :, [s]], state1[:, [s]], state2[[s]]] on the CPU (worker.py:426-430)."""
         s0, s1, s2 = self.batch_state
+        if self.state_arena is not None and self.state_arena.free_rows > 0:
+            return self.state_arena.export_slot(self.batch_state, slot)      # slot -> arena row, one strided copy per tensor
         parts = [s0[:, :, [slot], :], s1[:, [slot], :, :], s2[[slot]]]      # advanced indexing: fresh copies
         if self.state_cache_device is None:
             return parts
@@ -290,6 +296,9 @@ class Worker:
         s0, s1, s2 = self.batch_state
         if task.state is None:
             s0[:, :, slot].zero_(), s1[:, slot].zero_(), s2[slot].zero_()
+        elif hasattr(task.state, "install_into"):   # prefix-cache hit out of an HbmStateArena: row -> slot, one copy, unpin
+            task.state.install_into(self.batch_state, slot)
+            task.state.release()
         else:                                    # prefix-cache hit: [L,2,1,C], [L,1,H,64,64], [1]
             s0[:, :, [slot], :] = task.state[0].to(s0.device, non_blocking=True)
             s1[:, [slot], :, :] = task.state[1].to(s1.device, non_blocking=True)

@@ -212,21 +212,22 @@ def test_sample_topp_distribution(V, temp, top_p, top_k):
         assert bool((draws == int(p.argmax())).all())
 
 
-def test_prefix_cache_in_hbm_arena_round_trip():
-    """Row 8f-1 end to end: the worker exports a prefix state (device-resident), the arena-backed cache stores it
-    with one device-to-device copy, a later request with the same prefix starts from the arena's copy and
-    produces exactly the ids of the uncached request; evicting the entry does not disturb a state already
-    handed out."""
+@pytest.mark.parametrize("worker_has_arena", [False, True], ids=["clone_export", "arena_export"])
+def test_prefix_cache_in_hbm_arena_round_trip(worker_has_arena):
+    """Row 8f-1 end to end: the worker exports a prefix state (device-resident; with an arena straight into a free row:
+    ONE copy), the arena-backed cache keeps it, a later request with the same prefix gets a pinned row handle, the
+    worker installs row -> slot with ONE copy and produces exactly the ids of the uncached request; evicting the entry
+    while that hit is queued does not disturb it."""
     from chirrup_amd.core_structure import ModelLoadConfig, Task
-    from chirrup_amd.state_cache import HbmStateArena, SimpleStateCache
+    from chirrup_amd.state_cache import ArenaRef, HbmStateArena, SimpleStateCache
     from chirrup_amd.worker import Worker
 
     d, m = _tiny_model()
-    arena = HbmStateArena.for_model(m, capacity=2)
+    arena = HbmStateArena.for_model(m, capacity=3)            # max_size + one row for a state in flight
     cache = SimpleStateCache(max_size=2, arena=arena)
     cfg = ModelLoadConfig(model_path="unused", vocab_path="unused", vocab_size=320, head_size=64)
     tq, mq = queue.Queue(), queue.Queue()
-    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=4, model=m, tokenizer=_Tok())
+    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=4, model=m, tokenizer=_Tok(), state_arena=arena if worker_has_arena else None)
     w._init_worker()
     rng = np.random.default_rng(3)
     prompt = rng.integers(1, 320, 40).tolist()
@@ -244,18 +245,24 @@ def test_prefix_cache_in_hbm_arena_round_trip():
     t1 = mk(prompt, cache_prefill=True, cache_prefill_padding=3)
     ids1 = run(t1)
     exported = [x[1] for x in t1.output_queue.items if x[0] == "cache_prefill"]
-    assert len(exported) == 1 and exported[0]["state"][1].is_cuda
+    assert len(exported) == 1
+    ex_state = exported[0]["state"]
+    assert isinstance(ex_state, ArenaRef) == worker_has_arena
+    ex_tensors = ex_state.tensors() if worker_has_arena else ex_state
+    assert ex_tensors[1].is_cuda and tuple(ex_tensors[1].shape) == (2, 1, 2, 64, 64)
     seen = tuple(exported[0]["prefilled_tokens"])
-    cache.cache(seen, exported[0]["state"])
-    assert arena.free_rows == 1
-    rest, state, n = cache.check(list(prompt))
-    assert n == len(seen) and rest == prompt[n:] and state[0].is_cuda and tuple(state[1].shape) == (2, 1, 2, 64, 64)
-    assert torch.equal(state[1], exported[0]["state"][1]) and int(state[2][0]) == n
-    cache.cache((1, 2, 3), exported[0]["state"])
-    cache.cache((4, 5, 6), exported[0]["state"])            # evicts `seen`; `state` is a copy and stays valid
-    assert cache.check(list(prompt))[1] is None
-    ids2 = run(mk(rest, state=state))
+    cache.cache(seen, ex_state)                               # adopts the worker's row (arena export) or copies once
+    assert arena.free_rows == 2
+    rest, hit, n = cache.check(list(prompt))
+    assert n == len(seen) and rest == prompt[n:] and isinstance(hit, ArenaRef)
+    got = hit.tensors()
+    assert torch.equal(got[1], ex_tensors[1]) and torch.equal(got[0], ex_tensors[0]) and int(got[2][0]) == n
+    cache.cache((1, 2, 3), ex_tensors)
+    cache.cache((4, 5, 6), ex_tensors)                        # evicts `seen` while the hit is still queued: its row stays pinned
+    assert cache.check(list(prompt))[1] is None and arena.free_rows == 0
+    ids2 = run(mk(rest, state=hit))                           # Worker._install: row -> slot, then the pin is released
     assert ids2 == ids1 and len(ids1) == 8
+    assert arena.free_rows == 1 and not hit._live
 
 
 def test_worker_stress_protocol_consistency():
