@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mm8-leg", action="store_true", help="skip the second (uint8 FFN) model of the mm8 object")
+    p.add_argument("--no-engine-leg", action="store_true", help="skip the Worker-loop measurement of the engine object")
     p.add_argument("--no-penalties", action="store_true", help="plain arg-max instead of the worker's penalty tables + commit (round 1's step)")
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
@@ -393,6 +394,44 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None):
     return timed_region(timed_step, steps, dev), state      # barrier + sync on both sides, max over ranks
 
 
+def engine_iterations(model, B, a, dev, rank, steps):
+    """The same decode work through the PRODUCT's serving loop: chirrup_amd.worker.Worker (continuous batching over a slot
+    pool, bucketed HIP-graph decode, fused sampler, per-token host bookkeeping and messages, run-ahead scheduling) with B
+    concurrent greedy requests.  Timed like the bare step (barrier + sync on both sides, max over ranks); under
+    torch.distributed.run every rank is one worker process on its own GPU -- the engine's worker_mode="process" layout."""
+    import queue
+
+    from chirrup_amd.core_structure import ModelLoadConfig, Task
+    from chirrup_amd.dist_util import timed_region
+    from chirrup_amd.worker import Worker
+
+    class Tok:
+        def decode(self, ids, utf8_errors="strict"):
+            return "x"
+
+    class Sink:
+        def put_nowait(self, x):
+            pass
+
+    cfg = ModelLoadConfig(model_path="synthetic", vocab_path="none", vocab_size=65536, head_size=64)
+    tq, mq = queue.Queue(), queue.Queue()
+    w = Worker(f"worker_{rank}", [dev.index], cfg, tq, mq, None, batch_size=B + 1, model=model, tokenizer=Tok())
+    w.max_prefill_count = B                      # admit everybody at once for this measurement
+    w._init_worker()
+    g = torch.Generator().manual_seed(1234 + rank)
+    for _ in range(B):
+        tq.put(Task(output_queue=Sink(), task_event_queue=queue.Queue(), prompt_str="", state=None,
+                    prefill_tokens=torch.randint(1, 65536, (4,), generator=g).tolist(), temperature=0.0, top_p=0.0,
+                    frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=steps + 64))
+    for _ in range(10):                          # admission, the single-token prefill steps, graph capture, first decodes
+        w.step()
+    dt = timed_region(w.step, steps, dev)
+    w.shutdown_flag = True
+    del w
+    torch.cuda.empty_cache()
+    return dt
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -451,6 +490,11 @@ def main():
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
     wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
+    engine_dt = None
+    if not a.no_engine_leg and not a.no_graph and not a.no_fused:
+        del state
+        engine_dt = engine_iterations(model, B, a, dev, rank, a.steps)
+        state = make_state(model, B)
     gemm_t = gemm_shape_timings(model, B) if rank == 0 else {}
     mm8_obj = None
     if rank == 0 and world == 1 and not a.mm8 and not a.no_mm8_leg and not a.no_fused:
@@ -506,6 +550,12 @@ def main():
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if engine_dt is not None:
+            ems = engine_dt / a.steps * 1e3
+            out["engine"] = {"what": "the same batch through chirrup_amd.worker.Worker.step() (slot pool, graph decode, fused sampler, "
+                                     "host bookkeeping + messages, run-ahead), one worker process per GPU", "ms_per_iteration": round(ems, 4),
+                             "value": round(world * B * a.steps / engine_dt, 1), "unit": "tokens/s", "tps_per_request": round(1e3 / ems, 2),
+                             "vs_bare_step": round(ems / ms_per_step, 4)}
         if gemm_t:
             out["gemm_roofline"] = gemm_roofline_object(gemm_t, L)
         if mm8_obj is not None:

@@ -6,10 +6,14 @@ batch_size)`` -> asyncio.Task that completes when every worker has loaded; ``.co
 task queue, workers pull from it (replica data parallelism, worker k on GPU k); worker -> asyncio
 traffic goes through ``call_soon_threadsafe`` (ThreadSafeAsyncQueue, reference :30-57).
 
-Workers run as daemon threads like in the reference.  On a GIL build the per-iteration host work of
-8 workers serialises (~0.8 ms each per ~10 ms step here); the bench (one process per GPU) does not
-have that limit, and ``worker_factory`` lets a deployment substitute process-backed workers.
+``worker_mode="thread"`` (default) runs the workers as daemon threads like the reference, which relies on a
+free-threaded interpreter for that (README.md:52).  On a GIL build the per-iteration host work of N worker threads
+serialises (~1 ms each per ~7.5 ms step), so ``worker_mode="process"`` gives every worker its own process, spawned
+before the engine process makes any GPU call -- same messages, same pull-based balancing, queues over
+``multiprocessing`` (chirrup_amd/engine_process.py).  ``worker_mode="auto"`` picks "process" for more than one worker on
+an interpreter with a GIL.
 """
+import sys
 import asyncio
 import queue
 import threading
@@ -52,7 +56,17 @@ class ThreadSafeAsyncQueue:
 class AsyncEngineCore:
     LOAD_TIMEOUT_S = 300
 
-    def __init__(self, worker_factory: Optional[Callable[..., Any]] = None, tokenizer=None):
+    def __init__(self, worker_factory: Optional[Callable[..., Any]] = None, tokenizer=None, worker_mode: str = "thread",
+                 worker_kwargs: Optional[Dict[str, Any]] = None):
+        """worker_factory(**worker_args) -> object with .start(): defaults to chirrup_amd.worker.Worker; in process mode it is
+        called INSIDE the worker process and must be picklable (a module-level function).  worker_kwargs: extra Worker
+        arguments (e.g. run_ahead)."""
+        if worker_mode not in ("thread", "process", "auto"):
+            raise ValueError("worker_mode must be 'thread', 'process' or 'auto'")
+        self.worker_mode = worker_mode
+        self._worker_kwargs = dict(worker_kwargs or {})
+        self._router = None
+        self._result_q = None
         self.workers: List[Any] = []
         self.worker_threads: List[threading.Thread] = []
         self.task_queue: "queue.Queue[Task]" = queue.Queue()
@@ -66,11 +80,44 @@ class AsyncEngineCore:
         self._worker_factory = worker_factory
 
     def _make_worker(self, **kw):
+        kw.update(self._worker_kwargs)
         if self._worker_factory is not None:
             return self._worker_factory(**kw)
         from .worker import Worker
 
         return Worker(**kw)
+
+    @staticmethod
+    def _gil_enabled() -> bool:
+        return getattr(sys, "_is_gil_enabled", lambda: True)()
+
+    def _start_process_workers(self, worker_num, model_config, batch_size):
+        """One process per GPU, spawned before anything in THIS process has touched a GPU (it never has to)."""
+        from . import engine_process as ep
+
+        self._result_q, mp_task_q = ep.make_queues()
+        self._router = ep.ResultRouter(self._result_q, self.worker_event_queue, self._on_process_worker_exit)
+        self.task_queue = ep.ProcessTaskQueue(mp_task_q, self._router)
+        self.workers = ep.spawn_workers(worker_num, model_config, batch_size, self._worker_factory, self._worker_kwargs,
+                                        self._result_q, mp_task_q)
+        self._router.start()
+
+    def _on_process_worker_exit(self, worker_id: str, kind: str) -> None:
+        """Router thread: a worker process reported an error or ended.  Its requests are completed as aborted (its own
+        loop does that when it can; this covers a hard exit), and so are the queued ones when no worker is left."""
+        if self.is_shutdown or self._router is None:
+            return
+        for task in self._router.tasks_of(worker_id):
+            self._router.finish_aborted(task)
+        others = [w for w in self.workers if w.worker_id != worker_id and w.is_alive()]
+        if not others:
+            for task in self._router.pending():
+                self._router.finish_aborted(task)
+            while True:
+                try:
+                    self.task_queue.get_nowait()
+                except Exception:                # noqa: BLE001 -- queue.Empty
+                    break
 
     def init(self, worker_num: int, model_config: ModelLoadConfig, batch_size: int = 32) -> "asyncio.Task":
         if self.is_initialized:
@@ -89,9 +136,16 @@ class AsyncEngineCore:
 
             self.tokenizer = TRIE_TOKENIZER(model_config.vocab_path)
 
+        mode = self.worker_mode
+        if mode == "auto":
+            mode = "process" if (worker_num > 1 and self._gil_enabled()) else "thread"
+        self.worker_mode = mode
+
         async def wait_loaded():
             self.worker_id_set = {f"worker_{i}" for i in range(worker_num)}
-            for k, wid in enumerate(sorted(self.worker_id_set)):
+            if mode == "process":
+                self._start_process_workers(worker_num, model_config, batch_size)
+            for k, wid in enumerate(sorted(self.worker_id_set) if mode == "thread" else []):
                 w = self._make_worker(worker_id=wid, gpu_id=[k], model_config=model_config, task_queue=self.task_queue,
                                       master_event_queue=self.event_queue, worker_event_queue=self.worker_event_queue,
                                       batch_size=batch_size)
@@ -133,9 +187,15 @@ class AsyncEngineCore:
             raise RuntimeError("Engine has been shutdown")
         if not prefill_tokens:
             prefill_tokens = self.tokenizer.encode(prompt_str)
+        task_id = task_id or str(uuid.uuid4())
+        abort_channel = None
+        if self.worker_mode == "process":
+            from .engine_process import AbortChannel
+
+            abort_channel = AbortChannel(task_id, [w.abort_q for w in self.workers])
         return AsyncEngineCompletion(prompt_str=prompt_str, prefill_tokens=list(prefill_tokens), state=state,
                                      task_queue=self.task_queue, result_channel=ThreadSafeAsyncQueue(self.event_loop),
-                                     task_id=task_id or str(uuid.uuid4()), priority=priority, temperature=temperature,
+                                     task_id=task_id, priority=priority, temperature=temperature, task_event_queue=abort_channel,
                                      top_p=top_p, top_k=top_k, presence_penalty=presence_penalty,
                                      frequency_penalty=frequency_penalty, penalty_decay=penalty_decay,
                                      stop_tokens=stop_tokens, forbidden_tokens=forbidden_tokens, max_tokens=max_tokens,
@@ -162,6 +222,17 @@ class AsyncEngineCore:
         if self.is_shutdown:
             return
         self.is_shutdown = True
+        if self.worker_mode == "process" and self._router is not None:
+            for w in self.workers:
+                w.control_q.put({"type": "shutdown"})
+                w.abort_q.put(None)
+            for w in self.workers:
+                w.process.join(timeout=10)
+                if w.process.is_alive():
+                    w.process.terminate()
+            self._result_q.put(None)
+            self._router.join(timeout=5)
+            return
         for _ in range(max(1, len(self.workers))):       # every worker consumes one shutdown event
             self.event_queue.put_nowait({"type": "shutdown"})
         for t in self.worker_threads:

@@ -19,9 +19,10 @@ class AsyncEngineCompletion:
                  penalty_decay: float = DEFAULT_SAMPLING_CONFIG["penalty_decay"],
                  stop_tokens: Optional[List[int]] = DEFAULT_STOP_TOKENS, forbidden_tokens: Optional[List[int]] = None,
                  max_tokens: Optional[int] = DEFAULT_SAMPLING_CONFIG["max_tokens"], cache_prefill: bool = False,
-                 cache_prefill_padding: int = 0, return_logits: bool = False):
+                 cache_prefill_padding: int = 0, return_logits: bool = False, task_event_queue=None):
         self.task_id = task_id
-        self.task_event_queue: queue.Queue = queue.Queue()      # worker polls it for ("abort", None)
+        # the worker polls it for ("abort", None); a process-mode engine passes a channel that reaches the worker's process
+        self.task_event_queue = task_event_queue if task_event_queue is not None else queue.Queue()
         self._result_queue: asyncio.Queue = result_channel.queue
         self.task = Task(output_queue=result_channel, task_event_queue=self.task_event_queue, prompt_str=prompt_str,
                          prefill_tokens=prefill_tokens, state=state, task_id=task_id, priority=priority,

@@ -324,3 +324,65 @@ def test_worker_stress_protocol_consistency():
         outcomes.add(t.request_status)
     assert all(td["task"] is None for td in w.state_slot.values())
     assert {RequestStatus.FINISHED_LENGTH_CAPPED, RequestStatus.FINISHED_ABORTED} <= outcomes
+
+
+def test_worker_values_in_the_hand_written_gemm_regime():
+    """Round-1 advisor finding: the worker's VALUES were only checked on the L2/C128 toy model with 5 slots.  Here a
+    0.1B-shaped stack (C = 768, real LoRA ranks, every GEMM hand-written: skinny_min_embd = 0) serves 36 requests at
+    once -- 39 slots plus the parking slot, graph buckets up to 64 rows, prompts of 120-250 tokens through the chunked
+    prefill (up to 12 x 100 rows per forward) interleaved with decode steps -- and every request's greedy stream must
+    equal that request decoded ALONE (one prefill of the whole prompt, then single steps), up to the first step
+    whose solo top-2 logit margin is below fp16 noise (0.03: different batch compositions take different GEMM tiles)."""
+    from chirrup_amd.core_structure import ModelLoadConfig, Task
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from chirrup_amd.synth import make_state_dict
+    from chirrup_amd.worker import Worker
+
+    L, C, V, n_req, new = 3, 768, 1024, 36, 64
+    zd = make_state_dict(L, C, V, seed=21, varied_norms=True)
+    m = RWKV_x070(types.SimpleNamespace(vocab_size=V, head_size=64, MODEL_NAME="unused"), state_dict=zd, device="cuda:0",
+                  skinny_min_embd=0)
+    assert m._layers[0].rkv_t is not None
+    rng = np.random.default_rng(17)
+    prompts = [rng.integers(1, V, int(rng.integers(120, 251))).tolist() for _ in range(n_req)]
+    # solo decode: ids + the margin of every decision
+    solo = []
+    for p in prompts:
+        st = m.generate_zero_state(1)
+        lg = m.forward_seq_batch_seperate([p], st)
+        ids, margins = [], []
+        for _ in range(new):
+            top2 = torch.topk(lg[0].float(), 2).values
+            margins.append(float(top2[0] - top2[1]))
+            tok = int(lg[0].float().argmax())
+            ids.append(tok)
+            lg = m.forward_seq_batch_seperate([[tok]], st)
+        solo.append((ids, margins))
+    cfg = ModelLoadConfig(model_path="unused", vocab_path="unused", vocab_size=V, head_size=64)
+    tq, mq = queue.Queue(), queue.Queue()
+    w = Worker("w0", [0], cfg, tq, mq, None, batch_size=40, model=m, tokenizer=_Tok())
+    w.max_prefill_count = 12                            # up to 12 x 100 prompt rows per prefill forward (library-GEMM regime)
+    w._init_worker()
+    tasks = [Task(output_queue=_Sink(), task_event_queue=queue.Queue(), prompt_str="", prefill_tokens=list(p), state=None,
+                  temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=new)
+             for p in prompts]
+    for i, t in enumerate(tasks):                       # staggered arrivals: prefill chunks and decode rows share iterations
+        tq.put(t)
+        if i % 9 == 8:
+            for _ in range(4):
+                w.step()
+    for _ in range(5000):
+        if not w.step():
+            break
+    assert max(w._graphs) >= 32                         # the wide graph buckets were used
+    exact = 0
+    for t, (ids, margins) in zip(tasks, solo):
+        got = [x[1][0] for x in t.output_queue.items if x[0] == "token_generated"]
+        assert len(got) == new
+        for k in range(new):
+            if got[k] != ids[k]:
+                assert margins[k] < 0.03, (k, got, ids, margins[k])
+                break
+        else:
+            exact += 1
+    assert exact >= n_req * 3 // 4, exact               # near-ties are rare: most streams agree to the last token
