@@ -14,6 +14,8 @@
 // each) per lane and step; occurrence / alpha / penalty vectors are addressed through the row's
 // slot (slot_idx[row], or row when NULL) so that the worker's tables never move.
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 
 #include "../../include/chirrup_amd.h"
@@ -311,12 +313,12 @@ extern "C" int rwkv7_sample_topp(int n_rows, int V, const void *logits, const in
     if (!logits || !rows || !temperature || !top_p || !top_k || !uniform || !ids) return CHIRRUP_E_NULL;
     if (reinterpret_cast<uintptr_t>(logits) & 15) return CHIRRUP_E_ALIGN;
     const size_t lds = ((size_t)V * 2 + 15) / 16 * 16 + (size_t)kHistReplicas * 256 * 8 + 16 * 4 + 8 * 4;
-    static bool attr_set[32] = {};            // per device: one engine process may drive several GPUs
-    int dev = 0;
+    static std::atomic<bool> attr_set[32];    // per device: one engine process may drive several GPUs from several threads
+    int dev = 0;                              // (the attribute call is idempotent; the flag only saves repeating it)
     (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 31]) {
+    if (!attr_set[dev & 31].load(std::memory_order_acquire)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sample_topp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[dev & 31] = true;
+        attr_set[dev & 31].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL(sample_topp_kernel, dim3((unsigned)n_rows), dim3(kSampThreads), lds, static_cast<hipStream_t>(stream), V,
                        static_cast<const f16 *>(logits), rows, static_cast<const f16 *>(temperature),
