@@ -54,6 +54,8 @@ def parse():
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
+    p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
+    p.add_argument("--lora-m-split", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
     p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
@@ -171,7 +173,7 @@ def gemm_shape_timings(model, B):
     g = torch.Generator(device=dev)
     g.manual_seed(6)
     rnd = lambda *shape: torch.randn(shape, generator=g, device=dev).half()
-    gs = model.gemm_splits
+    gs, rh = model.gemm_splits, model.gemm_row_halves
     out = {}
     mixed, rkv = rnd(6, B, C), torch.empty((3, B, C), dtype=torch.float16, device=dev)
     dmax = lws[0].lora1.shape[1]
@@ -183,7 +185,7 @@ def gemm_shape_timings(model, B):
             probs = [(mixed[j], lw.rkv_t[j], rkv[j], None, None) for j in range(3)]
             probs += [(mixed[2 + j], lw.lora1[j, :ranks[j]], hid[j, :, :ranks[j]], None, "tanh" if j == 1 else ("sigmoid" if j == 3 else None))
                       for j in range(4)]
-            ops.skinny_group(probs, splits=gs["rkv"])
+            ops.skinny_group(probs, splits=gs["rkv"], row_halves=rh["rkv"])
 
     n_dn = sum(ranks)
     out["rkv_lora_down"] = (_replay_time(rkv_lora, L), (3 * C + n_dn) * C * 2 + 6 * B * C * 2 + B * (3 * C + n_dn) * 2,
@@ -191,7 +193,7 @@ def gemm_shape_timings(model, B):
 
     def lora_up():
         for lw in lws:
-            ops.skinny_bmm(hid, lw.lora2, lw.lbias, splits=1, k_of=ranks)
+            ops.skinny_bmm(hid, lw.lora2_t if lw.lora2_t is not None else lw.lora2, lw.lbias, splits=1, k_of=ranks, m_split=model.lora_up_m_split)
 
     out["lora_up"] = (_replay_time(lora_up, L), n_dn * C * 2 + B * n_dn * 2 + 4 * B * C * 2, "batched launch of the 4 LoRA up-projections, bias in the epilogue")
     x_c, x_4c = rnd(B, C), rnd(B, 4 * C)
@@ -199,17 +201,17 @@ def gemm_shape_timings(model, B):
 
     def att_out():
         for lw in lws:
-            ops.skinny_linear_partial(x_c, lw.O_t, gs["att_out"], pbuf)
+            ops.skinny_linear_partial(x_c, lw.O_t, gs["att_out"], pbuf, row_halves=rh["att_out"])
 
     out["att_output"] = (_replay_time(att_out, L), C * C * 2 + 2 * B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
     if lws[0].f_K_t is not None:
         def ffn_key():
             for lw in lws:
-                ops.skinny_linear(x_c, lw.f_K_t, act=1, splits=gs["ffn_key"])
+                ops.skinny_linear(x_c, lw.f_K_t, act=1, splits=gs["ffn_key"], row_halves=rh["ffn_key"])
 
         def ffn_value():
             for lw in lws:
-                ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf)
+                ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf, row_halves=rh["ffn_value"])
 
         out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "GEMM kernel + reduce with relu^2")
         out["ffn_value"] = (_replay_time(ffn_value, L), 4 * C * C * 2 + B * 4 * C * 2 + B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
@@ -469,6 +471,10 @@ def main():
     model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
     if a.splits is not None:
         model.gemm_splits.update(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (int(v) for v in a.splits.split(","))))
+    if a.row_halves is not None:
+        model.gemm_row_halves = dict(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (bool(int(v)) for v in a.row_halves.split(","))))
+    if a.lora_m_split is not None:
+        model.lora_up_m_split = bool(a.lora_m_split)
     if a.skinny_key is not None:
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:

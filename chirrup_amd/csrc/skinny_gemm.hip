@@ -76,10 +76,17 @@ __device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
 // Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
 // own L2: give XCD j a contiguous run of the K-slice-major tile order, so the x K-slice a workgroup re-reads is shared
 // by its L2 neighbours (ffn.value at bsz 200: x is 6.5 MB, a K-slice 0.8 MB; the L2 is 4 MB).
-__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch) {
-    const int G = gridDim.x, GS = G * gridDim.y, total = GS * gridDim.z;
-    const int L = blockIdx.x + G * blockIdx.y + GS * blockIdx.z;
+// halves = 2 (row halves, BatchStrides::m_split): the two workgroups of a tile's K-slice are neighbours in that order --
+// on the same XCD when the grid divides by 8 and dispatched together, so the W tile both stream is fetched from HBM once.
+__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch, int &half, const int halves) {
+    const int G = gridDim.x, GS = G * (gridDim.y / halves), total = G * gridDim.y * gridDim.z;
+    const int L = blockIdx.x + G * blockIdx.y + G * gridDim.y * blockIdx.z;
     int v = (total & 7) ? L : (L & 7) * (total >> 3) + (L >> 3);
+    half = 0;
+    if (halves == 2) {
+        half = v & 1;
+        v >>= 1;
+    }
     batch = v / GS;
     v -= batch * GS;
     kslice = v / G;
@@ -91,7 +98,11 @@ struct BatchStrides {
     int64_t x, w, y, bias;
     int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
     int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
-    int relu_sq;       // EPI_F16 only: y = relu(binary16(x.w + bias))^2 in the epilogue (unsplit launches need no reduce)
+    int relu_sq;       // EPI_F16: y = relu(binary16(x.w + bias))^2 in the epilogue
+    int m_split;       // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
+                       //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
+                       //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
+                       //    ring is deeper
 };
 
 // Problems that share only M, K, ldx, ldw and the split count (a "grouped" launch: R/K/V and the four LoRA
@@ -132,15 +143,21 @@ struct Tile {
     const f16 *bias;
     float *part;
     int Np, ldy, ngroup, kslice, batch;
+    int M;             // rows of x / y this workgroup works on (the launch's M, or its part under m_split)
+    int act;           // EPI_F16: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (as skinny_reduce_kernel)
     bool w_tiled;
 };
 
-template <bool W8>
+template <bool W8, int EPI, int MT>
 __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const void *Wv, f16 *Y, const int ldy, const f16 *bias,
-                                             float *part, const int M, const BatchStrides &bs, const GroupTable &gt) {
+                                             float *part, const int M, const int ldx, const BatchStrides &bs, const GroupTable &gt) {
     Tile t;
-    tile_of_block(t.ngroup, t.kslice, t.batch);
+    int half;
+    tile_of_block(t.ngroup, t.kslice, t.batch, half, bs.m_split ? 2 : 1);
     t.X = X, t.W = Wv, t.Y = Y, t.bias = bias, t.part = part, t.Np = N, t.ldy = ldy, t.w_tiled = bs.tiled != 0;
+    t.M = M, t.act = bs.relu_sq ? 1 : 0;
+    const int rows0 = half ? MT * 16 : 0;              // (m_split launches have M > 16 MT)
+    if (bs.m_split) t.M = half ? M - MT * 16 : MT * 16;
     if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
         int b = 0;
         while (b + 1 < gt.used && t.ngroup >= gt.first[b + 1]) b++;
@@ -149,13 +166,17 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
         t.X = gt.X[b], t.W = gt.W[b], t.Y = gt.Y[b], t.bias = gt.bias[b], t.part = gt.part[b];
         t.Np = gt.N[b], t.ldy = gt.ldy[b];
         t.w_tiled = gt.tiled[b] != 0;
+        t.act = gt.act[b];
     } else {
         t.X += t.batch * bs.x;
         t.W = static_cast<const unsigned char *>(Wv) + t.batch * bs.w * (W8 ? 1 : 2);
         if (Y) t.Y += t.batch * bs.y;
         if (bias) t.bias += t.batch * bs.bias;
-        if (part) t.part += (int64_t)t.batch * gridDim.y * M * N;
+        if (part) t.part += (int64_t)t.batch * (gridDim.y >> (bs.m_split ? 1 : 0)) * M * N;
     }
+    t.X += (int64_t)rows0 * ldx;
+    if (t.Y) t.Y += (int64_t)rows0 * t.ldy;
+    if (t.part) t.part += (int64_t)rows0 * t.Np;
     return t;
 }
 
@@ -275,9 +296,19 @@ __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 
 // workgroup store them as whole 512-B (f16: 256-B) row pieces.  Straight from the MFMA layout every store instruction
 // would touch 32 rows x 32 B (measured: ~8 us per launch of scattered stores).
 constexpr int kLd = kTileRows + 4;                     // floats per staged row: rows shift by 16 B -> conflict-free b128 writes
+__device__ __forceinline__ float apply_act(float v, const int act) {
+    if (act == 1) {
+        v = (float)(f16)v;                           // relu(fp16(y))**2, rwkv7.py:678
+        return v > 0.f ? v * v : 0.f;
+    }
+    if (act == 2) return tanhf((float)(f16)v);       // the LoRA hidden planes (rwkv7.py:626, :630), as skinny_reduce_kernel
+    if (act == 3) return 1.f / (1.f + __expf(-(float)(f16)v));
+    return v;
+}
+// M: rows this workgroup holds; plane_rows: rows of one K-slice's partial plane (the launch's M)
 template <int EPI, int THREADS>
 __device__ __forceinline__ void store_staged(const float *stage, const int M, const int n_first, const Tile &t, const int kslice,
-                                             const int relu_sq) {
+                                             const int plane_rows) {
     const int tid = threadIdx.x;
     const int c4 = tid & 31;                           // 4 columns per lane, 32 lanes per row, THREADS/32 rows per pass
     const int n = n_first + 4 * c4;
@@ -287,17 +318,10 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
         if (EPI == EPI_F16) {
             f16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float x = t.bias ? v[e] + (float)t.bias[n + e] : v[e];
-                if (relu_sq) {
-                    x = (float)(f16)x;               // relu(fp16(y))**2, rwkv7.py:678
-                    x = x > 0.f ? x * x : 0.f;
-                }
-                o[e] = (f16)x;
-            }
+            for (int e = 0; e < 4; e++) o[e] = (f16)apply_act(t.bias ? v[e] + (float)t.bias[n + e] : v[e], t.act);
             *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
         } else {
-            *reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * M + m) * t.Np + n) = v;
+            *reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * plane_rows + m) * t.Np + n) = v;
         }
     }
 }
@@ -319,13 +343,21 @@ __device__ __forceinline__ void stage_acc(float *stage, const f32x4 (&acc)[2][MT
 // issues its quarter of the x and of the W stage and waits for it with one counted vmcnt).  MT = 16-row tiles of x.
 // (Measured and dropped, profiles/r02_gemm_experiments.txt: x and W loader roles on two waves each with a deeper W ring
 // -- 6x slower, a loader wave that has to wait for its whole x stage every K-block is the critical path.)
+// Ring slots of the BN = 128 kernel: what fits in 160 KiB, at most 6 (at M = 200: 3, uint8 weights 4; half the rows: 5)
+template <int MT, bool W8>
+constexpr int ring_depth() {
+    constexpr int stage = MT * 16 * 128 + kTileRows * (W8 ? 64 : 128);
+    constexpr int d = (160 * 1024) / stage;
+    return d > 6 ? 6 : d;
+}
+
 template <int MT, bool W8, int EPI>
 __global__ __launch_bounds__(512) void ring_gemm_kernel(
     const int M, const int N, const int K, const int k_slice, const f16 *__restrict__ X, const int ldx,
     const void *__restrict__ Wv, const int64_t ldw, f16 *__restrict__ Y, const int ldy,
     const f16 *__restrict__ bias, float *__restrict__ part, const BatchStrides bs, const GroupTable gt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BN = 128, D = W8 ? 4 : 3;
+    constexpr int BN = 128, D = ring_depth<MT, W8>();
     constexpr int kXBytes = MT * 16 * 128;            // x K-block image
     constexpr int kWBytes = BN * (W8 ? 64 : 128);     // W K-block image: 128 rows x 64 k (binary16 or uint8)
     constexpr int kXRounds = (MT + 1) / 2;            // rounds of 256 lanes x 16 B = 32 rows; the last one is half a round when MT is odd
@@ -336,8 +368,9 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     const bool computes = wave < 4;
     const int lt = tid & 255, lw = wave & 3;
     const bool short_x = (MT & 1) && lw >= 2;         // this loader wave sits out the half round
-    const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
+    const Tile t = resolve_tile<W8, EPI, MT>(N, X, Wv, Y, ldy, bias, part, M, ldx, bs, gt);
     const int n_base = t.ngroup * BN;
+    if (n_base >= t.Np) return;                        // padding workgroup (launch_gemm rounds the grid up for the XCD map)
     const int n0 = n_base + wave * 32;
     const bool wave_live = computes && n0 < t.Np;
     const int k_begin = t.kslice * k_slice;
@@ -352,7 +385,7 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const Loader<W8> ld(t, M, ldx, ldw, K, lt);
+    const Loader<W8> ld(t, t.M, ldx, ldw, K, lt);
     auto stage = [&](int kb) {
         const int k0 = k_begin + kb * kKB;
         unsigned char *xb = xring + (kb % D) * kXBytes, *wb = wring + (kb % D) * kWBytes;
@@ -389,9 +422,9 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     if (!computes) return;                             // loader waves are done; finished waves do not count in s_barrier
     float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*16 rows x 528 B <= its size)
     __syncthreads();                                   // every compute wave is past its last fragment read
-    if (wave_live) stage_acc<MT>(stg, acc, M, wave * 32, c, q);
+    if (wave_live) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
     __syncthreads();
-    store_staged<EPI, 256>(stg, M, n_base, t, t.kslice, bs.relu_sq);
+    store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,8 +449,9 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
     const bool xrole = wave < 4;
     const int lt = tid & 255, lw = wave & 3;
     const bool short_x = (MT & 1) && lw >= 2;
-    const Tile t = resolve_tile<W8>(N, X, Wv, Y, ldy, bias, part, M, bs, gt);
+    const Tile t = resolve_tile<W8, EPI, MT>(N, X, Wv, Y, ldy, bias, part, M, ldx, bs, gt);
     const int n_base = t.ngroup * BN;
+    if (n_base >= t.Np) return;                        // padding workgroup (launch_gemm rounds the grid up for the XCD map)
     const int n0 = n_base + wave * 32;
     const bool wave_live = n0 < t.Np;
     const int k_begin = t.kslice * k_slice;
@@ -426,7 +460,7 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
     const int nkb = k_end > k_begin ? (k_end - k_begin) / kKB : 0;
     unsigned char *const xring = smem, *const wring = smem + XD * kXBytes;
 
-    const Loader<W8> ld(t, M, ldx, ldw, K, lt);
+    const Loader<W8> ld(t, t.M, ldx, ldw, K, lt);
 
     f32x4 acc[2][MT];
 #pragma unroll
@@ -476,9 +510,9 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
     __syncthreads();                                   // every wave is past its last fragment read (no LDS-DMA is pending)
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        if ((wave >> 2) == half && wave_live) stage_acc<MT>(stg, acc, M, (wave & 3) * 32, c, q);
+        if ((wave >> 2) == half && wave_live) stage_acc<MT>(stg, acc, t.M, (wave & 3) * 32, c, q);
         __syncthreads();
-        store_staged<EPI, 512>(stg, M, n_base + half * kTileRows, t, t.kslice, bs.relu_sq);
+        store_staged<EPI, 512>(stg, t.M, n_base + half * kTileRows, t, t.kslice, M);
         if (half == 0) __syncthreads();
     }
 }
@@ -661,7 +695,7 @@ int pick_splits(int bn, int N, int K, int requested, int Z = 1) {
         return s < 1 ? 1 : s;
     }
     const int ngroups = Z * ((N + bn - 1) / bn);
-    int s = (256 + ngroups - 1) / ngroups;             // aim at >= 256 workgroups
+    int s = (256 + ngroups / 2) / ngroups;             // aim at ~256 workgroups (one per CU)
     const int max_s = K / 256 > 0 ? K / 256 : 1;       // keep >= 4 K-blocks per slice
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -673,7 +707,11 @@ size_t lds_bytes(int bn, int MT, bool w8) {
     const size_t x = (size_t)MT * 16 * 128, stage = (size_t)MT * 16 * kLd * sizeof(float);
     size_t ring;
     if (bn == 256) ring = 2 * x + (size_t)(w8 ? 5 : 3) * 2 * kTileRows * (w8 ? 64 : 128);
-    else ring = (size_t)(w8 ? 4 : 3) * (x + (size_t)kTileRows * (w8 ? 64 : 128));
+    else {
+        const size_t st = x + (size_t)kTileRows * (w8 ? 64 : 128);
+        size_t d = (160 * 1024) / st;                  // ring_depth<MT, W8>()
+        ring = (d > 6 ? 6 : d) * st;
+    }
     return ring > stage ? ring : stage;
 }
 
@@ -684,6 +722,9 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
                 int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
                 const GroupTable &gt = GroupTable{}) {
     const size_t lds = lds_bytes(bn, MT, W8);
+    // tile_of_block deals contiguous runs of tiles to the XCDs only when the workgroup count divides by 8: round the
+    // N-group count up (the extra workgroups leave at once)
+    while ((grid.x * grid.y * grid.z) & 7) grid.x++;
 #define GO_K(KERN, MTV)                                                                                                   \
     do {                                                                                                                  \
         auto kern = KERN<MTV, W8, EPI>;                                                                                   \
@@ -790,9 +831,20 @@ extern "C" int64_t skinny_gemm_workspace_bytes(int M, int N, int K, int splits) 
     return s > 1 ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
 }
 
+// Row halves (row_halves = 1 in the entry points below, honoured for M > 32 with the 128-column kernel): every tile and
+// K-slice is worked on by TWO workgroups, one per half of the rows.  That doubles the workgroups without doubling the
+// partial planes (or makes an unsplit launch fill the chip: no partials, no reduce launch at all); the price is that both
+// stream the W tile -- neighbours in dispatch order on one XCD, so HBM sees it once.  With splits = 0 the split count
+// is chosen for twice the tiles.
+namespace {
+inline bool use_halves(int row_halves, int M, int bn) { return row_halves && M > 32 && bn == 128; }
+inline int tiles_of(int M, bool halves) { return halves ? ((M + 15) / 16 + 1) / 2 : (M + 15) / 16; }
+}  // namespace
+
 // Y = act(X . W^T + bias);  W binary16 [N][K] (row stride ldw).  act: 0 none, 1 relu^2.
 extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
-                               const void *bias, void *Y, int ldy, int act, int splits, void *workspace, void *stream) {
+                               const void *bias, void *Y, int ldy, int act, int splits, int row_halves, void *workspace,
+                               void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N || (ldx & 7) || (ldw & 7) || (ldy & 3))
         return CHIRRUP_E_SHAPE;
     if (act < 0 || act > 1) return CHIRRUP_E_UNSUPPORTED;
@@ -800,14 +852,16 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     if (!X || !W || !Y) return CHIRRUP_E_NULL;
     if (mis16(X) || mis16(W) || (reinterpret_cast<uintptr_t>(Y) & 7) || (reinterpret_cast<uintptr_t>(bias) & 7)) return CHIRRUP_E_ALIGN;
     const int bn = choose_bn(N);
-    const int s = pick_splits(bn, N, K, splits);
+    const bool halves = use_halves(row_halves, M, bn);
+    const int s = pick_splits(bn, N, K, splits, halves ? 2 : 1);
     const bool partial = s > 1;                        // unsplit: bias and relu^2 run in the kernel's own epilogue
     if (partial && !workspace) return CHIRRUP_E_NULL;
-    const int MT = (M + 15) / 16;
+    const int MT = tiles_of(M, halves);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((N + bn - 1) / bn, s);
+    const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
+    bs.m_split = halves ? 1 : 0;
     bs.relu_sq = (!partial && act == 1) ? 1 : 0;
     int rc = partial ? launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                        (const f16 *)bias, (float *)workspace, bs)
@@ -833,17 +887,20 @@ extern "C" int64_t skinny_gemm_batched_workspace_bytes(int Z, int M, int N, int 
 extern "C" int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, int64_t x_bs, const void *W,
                                        int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy,
                                        int64_t y_bs, int act, int splits, void *workspace, void *stream) {
-    return skinny_gemm_f16_grouped(Z, M, N, K, nullptr, X, ldx, x_bs, W, ldw, w_bs, bias, bias_bs, Y, ldy, y_bs, act, splits,
+    return skinny_gemm_f16_grouped(Z, M, N, K, nullptr, X, ldx, x_bs, W, ldw, w_bs, 0, bias, bias_bs, Y, ldy, y_bs, act, splits, 0,
                                    workspace, stream);
 }
 
 // As skinny_gemm_f16_batched, with a reduction length per problem: problem z multiplies only the first k_of[z] columns
 // of X[z] and W[z] (k_of[z] <= K, a multiple of 64; k_of == NULL: K for all).  For operands that are zero-padded to a
 // common K (RWKV-7's LoRA ranks: 96 / 128 / 128 / 480 packed as 512) the padding is then never read.  Z <= 8, and
-// splits must be 1 when k_of is given.
+// splits must be 1 when k_of is given.  w_tiled: every W[z] is a tile image of the [N][K] matrix (skinny_tile_weight).
+// m_split = 1 (unsplit launches without activation only): each problem runs as two sets of workgroups over the upper and
+// lower half of the rows -- twice the workgroups and a deeper operand ring for problems with few K-blocks.
 extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs,
-                                       const void *W, int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y,
-                                       int ldy, int64_t y_bs, int act, int splits, void *workspace, void *stream) {
+                                       const void *W, int64_t ldw, int64_t w_bs, int w_tiled, const void *bias, int64_t bias_bs,
+                                       void *Y, int ldy, int64_t y_bs, int act, int splits, int m_split, void *workspace,
+                                       void *stream) {
     if (Z <= 0 || Z > 65535 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N ||
         (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
         return CHIRRUP_E_SHAPE;
@@ -854,11 +911,15 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
     const int s = pick_splits(bn, N, K, splits, Z);
     const bool partial = s > 1 || act != 0;
     if (partial && !workspace) return CHIRRUP_E_NULL;
-    const int MT = (M + 15) / 16;
+    if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    const bool halves = !partial && use_halves(m_split, M, bn);
+    const int MT = tiles_of(M, halves);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((N + bn - 1) / bn, s, Z);
+    const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s, Z);
     BatchStrides bs{};
     bs.x = x_bs, bs.w = w_bs, bs.y = y_bs, bs.bias = bias_bs;
+    bs.tiled = w_tiled ? 1 : 0;
+    bs.m_split = halves ? 1 : 0;
     if (k_of) {
         if (Z > 8 || splits != 1) return CHIRRUP_E_UNSUPPORTED;
         for (int z = 0; z < Z; z++) {
@@ -882,7 +943,7 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
 }
 
 namespace {
-int group_bn_and_splits(int count, const chirrup_gemm_problem *problems, int K, int splits, int &s_out) {
+int group_bn_and_splits(int count, const chirrup_gemm_problem *problems, int K, int splits, int &s_out, bool halves = false) {
     int max_n = 0, sum_groups = 0;
     for (int i = 0; i < count; i++) max_n = problems[i].n > max_n ? problems[i].n : max_n;
     const int bn = choose_bn(max_n);
@@ -890,7 +951,8 @@ int group_bn_and_splits(int count, const chirrup_gemm_problem *problems, int K, 
     if (splits > 0) {
         s_out = splits;
     } else {                                           // as pick_splits, over the launch's exact tile list
-        int s = (256 + sum_groups - 1) / sum_groups;
+        if (halves) sum_groups *= 2;
+        int s = (256 + sum_groups / 2) / sum_groups;
         const int max_s = K / 256 > 0 ? K / 256 : 1;
         s = s > max_s ? max_s : (s < 1 ? 1 : s);
         while (s > 1 && (K / kKB) % s) s--;
@@ -909,18 +971,21 @@ extern "C" int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_ge
     return b;
 }
 
-// Up to 8 GEMMs that share M, K, the row strides of x and W and the split count, in ONE launch (+ one reduce launch):
-// y_i = act_i(x_i . w_i^T + bias_i).  Always goes through split-K partials (splits >= 1) so that the activations run in
-// the reduce kernel; blockIdx.x runs over the exact list of the problems' N-groups.
+// Up to 8 GEMMs that share M, K, the row strides of x and W and the split count, in ONE launch: y_i = act_i(x_i . w_i^T +
+// bias_i); blockIdx.x runs over the exact list of the problems' N-groups.  Unsplit (splits = 1, or the library's choice
+// with row_halves): bias and activation run in the GEMM epilogue; split: through binary32 partials + one reduce launch.
 extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw,
-                                     int splits, void *workspace, void *stream) {
+                                     int splits, int row_halves, void *workspace, void *stream) {
     if (count <= 0 || count > 8 || !problems) return CHIRRUP_E_SHAPE;
     if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || splits < 0 ||
         (splits > 0 && ((K / kKB) % splits)))
         return CHIRRUP_E_SHAPE;
-    if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255)) return workspace ? CHIRRUP_E_ALIGN : CHIRRUP_E_NULL;
-    int s;
-    const int bn = group_bn_and_splits(count, problems, K, splits, s);
+    int s, s_plain;
+    group_bn_and_splits(count, problems, K, splits, s_plain);
+    const int bn = group_bn_and_splits(count, problems, K, splits, s, true);
+    const bool halves = use_halves(row_halves, M, bn);
+    if (!halves) s = s_plain;
+    if (s > 1 && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 255))) return workspace ? CHIRRUP_E_ALIGN : CHIRRUP_E_NULL;
     GroupTable gt{};
     gt.used = count;
     int max_n = 0;
@@ -934,16 +999,23 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
         gt.bias[i] = static_cast<const f16 *>(q.bias), gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act;
         if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
         gt.tiled[i] = q.w_tiled ? 1 : 0;
-        gt.part[i] = reinterpret_cast<float *>(ws);
-        ws += ((int64_t)s * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
+        if (s > 1) {
+            gt.part[i] = reinterpret_cast<float *>(ws);
+            ws += ((int64_t)s * M * q.n * (int64_t)sizeof(float) + 255) / 256 * 256;
+        }
         max_n = q.n > max_n ? q.n : max_n;
         gt.first[i + 1] = gt.first[i] + (q.n + bn - 1) / bn;
     }
-    const int MT = (M + 15) / 16;
+    const int MT = tiles_of(M, halves);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(gt.first[count], s, 1);
+    const dim3 grid(gt.first[count], halves ? 2 * s : s, 1);
+    BatchStrides bs{};
+    bs.m_split = halves ? 1 : 0;
+    if (s == 1)
+        return launch_gemm<false, EPI_F16>(bn, MT, grid, st, M, max_n, K, K, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0], nullptr,
+                                           nullptr, bs, gt);
     int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
-                                             nullptr, gt.part[0], BatchStrides{}, gt);
+                                             nullptr, gt.part[0], bs, gt);
     if (rc) return rc;
     const int64_t total = (int64_t)M * max_n / 4;
     hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, M, max_n, s,
@@ -953,18 +1025,20 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
-                                       int splits, float *partials, void *stream) {
+                                       int splits, int row_halves, float *partials, void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7))
         return CHIRRUP_E_SHAPE;
     if (!X || !W || !partials) return CHIRRUP_E_NULL;
     if (mis16(X) || mis16(W) || mis16(partials)) return CHIRRUP_E_ALIGN;
     if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     const int bn = choose_bn(N);
-    const int s = pick_splits(bn, N, K, splits);
-    const int MT = (M + 15) / 16;
-    const dim3 grid((N + bn - 1) / bn, s);
+    const bool halves = use_halves(row_halves, M, bn);
+    const int s = pick_splits(bn, N, K, splits, halves ? 2 : 1);
+    const int MT = tiles_of(M, halves);
+    const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
+    bs.m_split = halves ? 1 : 0;
     const int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
                                                    W, ldw, nullptr, N, nullptr, partials, bs);
     return rc ? -1000 - rc : s;

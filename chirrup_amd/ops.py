@@ -386,9 +386,10 @@ def _weight_args(weight, K: int, name: str = "weight"):
     return weight.shape[0], weight.data_ptr(), weight.stride(0), 0
 
 
-def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None):
+def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, row_halves: bool = False):
     """y = act(x @ weight.T + bias) through the hand-written skinny-M MFMA GEMM (x [M<=256, K] fp16,
-    weight [N, K] fp16 row-major, may be a row-strided view, or a TiledWeight).  act 1 = relu(.)**2."""
+    weight [N, K] fp16 row-major, may be a row-strided view, or a TiledWeight).  act 1 = relu(.)**2.
+    row_halves: two workgroups per tile, one per half of the rows (include/chirrup_amd.h)."""
     if x.dim() != 2 or not x.is_cuda or x.dtype != torch.float16 or x.stride(1) != 1:
         raise _lib.ChirrupAmdError("skinny_linear: expected x [M,K] GPU fp16 with unit inner stride")
     M, K = x.shape
@@ -403,23 +404,48 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None)
     if bias is not None:
         _chk16("bias", bias, N)
     rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, _ptr(bias),
-                           out.data_ptr(), out.stride(0), act, splits, _ptr(ws), _stream())
+                           out.data_ptr(), out.stride(0), act, splits, 1 if row_halves else 0, _ptr(ws), _stream())
     _lib.check(rc, "skinny_gemm_f16")
     return out
 
 
-def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_of=None):
-    """Batched skinny_linear in one launch: x [Z, M<=256, K], weight [Z, N, K] (K % 64 == 0), bias [Z, 1, N] or
-    [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA planes.
-    k_of: optional per-problem reduction lengths (multiples of 64, <= K; needs splits=1): zero-padded tails of
-    x / weight beyond k_of[z] are not read."""
-    if x.dim() != 3 or weight.dim() != 3 or x.shape[0] != weight.shape[0] or x.shape[2] != weight.shape[2]:
+def tile_weight_batch(weight: torch.Tensor) -> "TiledWeightBatch":
+    """weight [Z, N, K] fp16 -> Z tile images (tile_weight of each matrix) in one tensor, for skinny_bmm."""
+    Z, N, K = weight.shape
+    data = torch.stack([tile_weight(weight[z]).data for z in range(Z)])
+    return TiledWeightBatch(data, Z, N, K)
+
+
+class TiledWeightBatch:
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data, z, n, k):
+        self.data, self.shape = data, (z, n, k)
+
+    def __getitem__(self, sl):                           # weight[p0:] -- a leading slice of the problems
+        d = self.data[sl]
+        return TiledWeightBatch(d, d.shape[0], self.shape[1], self.shape[2])
+
+
+def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_of=None, m_split: bool = False):
+    """Batched skinny_linear in one launch: x [Z, M<=256, K], weight [Z, N, K] (K % 64 == 0; or a TiledWeightBatch),
+    bias [Z, 1, N] or [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA
+    planes.  k_of: optional per-problem reduction lengths (multiples of 64, <= K; needs splits=1): zero-padded tails of
+    x / weight beyond k_of[z] are not read.  m_split: two workgroup sets per problem over the two halves of the rows
+    (unsplit, no activation: problems of few K-blocks)."""
+    w_tiled = isinstance(weight, TiledWeightBatch)
+    if w_tiled:
+        wshape, weight = weight.shape, weight.data
+        wstrides = (weight.stride(0), wshape[2], 1)
+    else:
+        wshape, wstrides = tuple(weight.shape), tuple(weight.stride()) if weight.dim() == 3 else ()
+    if x.dim() != 3 or len(wshape) != 3 or x.shape[0] != wshape[0] or x.shape[2] != wshape[2]:
         raise _lib.ChirrupAmdError("skinny_bmm: expected x [Z,M,K], weight [Z,N,K]")
-    for name, t in (("x", x), ("weight", weight)):
-        if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1:
+    for name, t, inner in (("x", x, x.stride(2)), ("weight", weight, wstrides[2])):
+        if not t.is_cuda or t.dtype != torch.float16 or inner != 1:
             raise _lib.ChirrupAmdError(f"{name}: expected GPU fp16 with unit inner stride")
     Z, M, K = x.shape
-    N = weight.shape[1]
+    N = wshape[1]
     if out is None:
         out = torch.empty((Z, M, N), dtype=torch.float16, device=x.device)
     bias_bs = 0
@@ -436,9 +462,9 @@ def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_
         if len(k_of) != Z:
             raise _lib.ChirrupAmdError("k_of: one reduction length per problem")
         karr = (ctypes.c_int * Z)(*[int(k) for k in k_of])
-    rc = L.skinny_gemm_f16_grouped(Z, M, N, K, karr, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), weight.stride(1),
-                                   weight.stride(0), _ptr(bias), bias_bs, out.data_ptr(), out.stride(1), out.stride(0), act,
-                                   splits, ws.data_ptr(), _stream())
+    rc = L.skinny_gemm_f16_grouped(Z, M, N, K, karr, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), wstrides[1],
+                                   wstrides[0], 1 if w_tiled else 0, _ptr(bias), bias_bs, out.data_ptr(), out.stride(1),
+                                   out.stride(0), act, splits, 1 if m_split else 0, ws.data_ptr(), _stream())
     _lib.check(rc, "skinny_gemm_f16_grouped")
     return out
 
@@ -457,8 +483,8 @@ def gemm_splits(N: int, K: int, Z: int = 1, splits: int = 0) -> int:
     return _lib.load().skinny_gemm_splits(N, K, Z, splits)
 
 
-def skinny_group(problems, splits: int = 0):
-    """Several GEMMs over the same rows in ONE launch (+ one reduce): ``problems`` is a list of
+def skinny_group(problems, splits: int = 0, row_halves: bool = False):
+    """Several GEMMs over the same rows in ONE launch (+ one reduce launch when K is split): ``problems`` is a list of
     (x [M,K], weight [N,K], out [M,N], bias [N] or None, act in {None, "relu_sq", "tanh", "sigmoid"}); all x share
     M <= 256, K (% 64 * splits == 0) and their row stride, all weights share their row stride.  Writes the outs.
     splits = 0: the library's choice."""
@@ -487,11 +513,11 @@ def skinny_group(problems, splits: int = 0):
     ws = _workspace(nbytes + 256, x0.device)
     base = (ws.data_ptr() + 255) // 256 * 256
     rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), ldw0 if ldw0 is not None else K, splits,
-                                 base, _stream())
+                                 1 if row_halves else 0, base, _stream())
     _lib.check(rc, "skinny_gemm_f16_group")
 
 
-def skinny_linear_partial(x, weight, splits: int, partials):
+def skinny_linear_partial(x, weight, splits: int, partials, row_halves: bool = False):
     """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
     [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""
     M, K = x.shape
@@ -502,7 +528,7 @@ def skinny_linear_partial(x, weight, splits: int, partials):
     want = L.skinny_gemm_workspace_bytes(M, N, K, splits) or M * N * 4
     if partials.numel() * 4 < want:
         raise _lib.ChirrupAmdError("partials buffer too small")
-    rc = L.skinny_gemm_f16_partial(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, splits,
+    rc = L.skinny_gemm_f16_partial(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, splits, 1 if row_halves else 0,
                                    partials.data_ptr(), _stream())
     if rc <= 0:
         raise _lib.ChirrupAmdError(f"skinny_gemm_f16_partial: {rc}")

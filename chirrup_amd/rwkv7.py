@@ -86,7 +86,7 @@ class _Layer:
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
                  "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows",
-                 "rkv_t", "O_t", "f_K_t", "f_V_t", "f8_tiled")
+                 "rkv_t", "O_t", "f_K_t", "f_V_t", "lora2_t", "f8_tiled")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -145,6 +145,7 @@ class _Layer:
         self.O_t = ops.tile_weight(self.O) if ok(self.O) else None
         self.f_K_t = ops.tile_weight(self.f_K) if ok(self.f_K) else None
         self.f_V_t = ops.tile_weight(self.f_V.t()) if (self.f_V is not None and ok(self.f_V.t())) else None
+        self.lora2_t = ops.tile_weight_batch(self.lora2) if ok(self.lora2[0]) else None      # +8 * C * Dmax B per layer
 
     def quantize_ffn(self, z, i, tile: bool = False):
         """mm8 (w8a16) channel-mix: quantise ffn.key / ffn.value like the reference's quantize_weight
@@ -200,6 +201,7 @@ class RWKV_x070:
         self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
+        self.lora_up_m_split = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
@@ -209,6 +211,10 @@ class RWKV_x070:
         self.skinny_ffn_key = True                       # ffn.key + relu^2 through the same kernel (split-K 2, fused epilogue)
         # K-split factors of the hand-written GEMMs (0 = the library's choice); tuning knobs for tools/ and bench.py
         self.gemm_splits = {"rkv": 0, "att_out": 0, "ffn_key": 0, "ffn_value": 0}
+        # ... and two workgroups per tile, one per half of the rows (include/chirrup_amd.h: row_halves), for >= 128 rows:
+        # att.output then needs 4 partial planes instead of 8, ffn.key none (no reduce launch).  A/B at 7.2B / bsz 200 on one
+        # box (profiles/r02_gemm_experiments.txt section 10): step 7.27 -> 7.09 ms; R/K/V and ffn.value lose with it.
+        self.gemm_row_halves = {"rkv": False, "att_out": True, "ffn_key": True, "ffn_value": False}
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
@@ -224,7 +230,7 @@ class RWKV_x070:
                 if ffn_dtype == torch.int8:
                     lw.quantize_ffn(self.z, i, tile=self.tiled_weights)
                 lw.f_V_rows = lw.f_V.contiguous() if self.sparse_bsz1 else None
-                lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = None
+                lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = lw.lora2_t = None
                 if self.tiled_weights and self.n_embd >= self.skinny_min_embd:
                     lw.tile_for_ring()
             torch.cuda.empty_cache()
@@ -417,6 +423,7 @@ class RWKV_x070:
         hw = self.skinny_ffn_value and self.skinny_min_rows <= rows <= 256 and C >= self.skinny_min_embd
         use_parts = hw and self.ffn_dtype == torch.float16
         gs = self.gemm_splits
+        rh = self.gemm_row_halves if rows >= 128 else dict.fromkeys(self.gemm_row_halves, False)
         pbuf = (torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), dtype=torch.float32, device=dev)
                 if use_parts else None)
         pbuf_o = (torch.empty((ops.gemm_splits(C, C, 1, gs["att_out"]), rows, C), dtype=torch.float32, device=dev)
@@ -467,8 +474,10 @@ class RWKV_x070:
                 for j in range(p0, 4):
                     kj = lw.lora_k[j]
                     probs.append((mixed[2 + j], lw.lora1[j, :kj], hid[j - p0, :, :kj], None, ("tanh" if j == 1 else ("sigmoid" if j == 3 else None))))
-                ops.skinny_group(probs, splits=gs["rkv"])
-                up = ops.skinny_bmm(hid[: 4 - p0], lw.lora2[p0:], lw.lbias[p0:], splits=1, k_of=lw.lora_k[p0:])
+                ops.skinny_group(probs, splits=gs["rkv"], row_halves=rh["rkv"])
+                # the up-projections: 4 x C/128 tiles of 2..8 K-blocks -- two row halves per tile fill the chip
+                up = ops.skinny_bmm(hid[: 4 - p0], (lw.lora2_t if lw.lora2_t is not None else lw.lora2)[p0:], lw.lbias[p0:], splits=1,
+                                    k_of=lw.lora_k[p0:], m_split=self.lora_up_m_split)
                 side = None
             if side is not None:
                 side.wait_stream(main)
@@ -511,7 +520,7 @@ class RWKV_x070:
             prev = s0[i][1]
             q8_out = (lw.f_K8.ry, lw.f_K8.my, xs_k, S_k) if q8 else None
             if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
-                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, gs["att_out"], pbuf_o)   # reduce folded into the LN below
+                aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, gs["att_out"], pbuf_o, row_halves=rh["att_out"])   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
                                prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts, mm8_out=q8_out)
             else:
@@ -531,7 +540,8 @@ class RWKV_x070:
                 delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)
             else:
                 if use_parts and self.skinny_ffn_key and rows >= self.skinny_wide_rows:
-                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=gs["ffn_key"])
+                    kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=gs["ffn_key"],
+                                           row_halves=rh["ffn_key"])
                 else:
                     kf = F.linear(kin[0], lw.f_K)
                     ops.relu_sq_(kf)
@@ -541,7 +551,7 @@ class RWKV_x070:
                     # K = 4C >> N = C at decode batch sizes: the hand-written LDS-DMA ring GEMM streams this
                     # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200);
                     # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
-                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), gs["ffn_value"], pbuf), None
+                    dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), gs["ffn_value"], pbuf, row_halves=rh["ffn_value"]), None
                 else:
                     delta = kf @ lw.f_V
         if dparts is not None and (T > 1 and not full_output):

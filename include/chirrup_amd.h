@@ -205,7 +205,7 @@ int skinny_gemm_splits(int N, int K, int Z, int splits);
  * [splits][M][N] in `partials` for the consumer to sum (see rwkv7_add_ln_mix). Returns the split count used
  * (> 0) or a negative CHIRRUP_E_* / positive hipError_t is NOT distinguishable here, so errors are < 0 only. */
 int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, int splits,
-                            float *partials, void *stream);
+                            int row_halves, float *partials, void *stream);
 /* Z independent skinny GEMMs in ONE launch (RWKV-7's receptance/key/value projections, Albatross/rwkv7.py:603-605,
  * and its four LoRA pairs, :626-637): Y[z] = act(X[z] . W[z]^T + bias[z]).  Problem z's operands start z * (their
  * batch stride, in elements) after problem 0's; bias may be NULL.  act: 0 none, 1 relu(.)^2, 4 + p: LoRA hidden
@@ -217,16 +217,27 @@ int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X, int ldx, 
                             int splits, void *workspace, void *stream);
 /* The same with a reduction length per problem: problem z uses only the first k_of[z] columns of X[z] and W[z]
  * (k_of[z] <= K, multiple of 64; NULL = K for all).  Operands zero-padded to a common K (the LoRA ranks 96/128/128/480
- * packed as 512) are then not streamed beyond their real rank.  Z <= 8; splits must be 1 when k_of is given. */
+ * packed as 512) are then not streamed beyond their real rank.  Z <= 8; splits must be 1 when k_of is given.
+ * w_tiled: every W[z] is the tile image (skinny_tile_weight) of its [N][K] matrix, N % 128 == 0.
+ * row_halves: as below, honoured for splits == 1 and act == 0 (the LoRA up-projections: 4 x 32 tiles of 2..8 K-blocks get
+ * twice the workgroups and, with half the x image per stage, a deeper operand ring). */
 int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs, const void *W,
-                            int64_t ldw, int64_t w_bs, const void *bias, int64_t bias_bs, void *Y, int ldy, int64_t y_bs,
-                            int act, int splits, void *workspace, void *stream);
+                            int64_t ldw, int64_t w_bs, int w_tiled, const void *bias, int64_t bias_bs, void *Y, int ldy,
+                            int64_t y_bs, int act, int splits, int row_halves, void *workspace, void *stream);
 /* Up to 8 GEMMs that share M, K, the row strides of x and W (ldx, ldw) and the split count, in ONE launch plus one
  * reduce launch: y_i = act_i(x_i . w_i^T + bias_i), w_i binary16 [n_i][K].  This is one RWKV-7 layer's receptance /
  * key / value projections together with its four LoRA down-projections and their activations (Albatross/rwkv7.py:
  * 625-637): seven independent GEMMs over the same token rows that the reference issues one by one.
  * act: 0 none, 1 relu(.)^2, 2 tanh, 3 sigmoid (applied to the binary16-rounded sum, like a separate torch op).
- * splits = 0: the library's choice.  workspace: skinny_gemm_group_workspace_bytes(...) bytes, 256-byte aligned. */
+ * splits = 0: the library's choice.  Unsplit launches apply bias / activation in the GEMM epilogue; split ones go through
+ * binary32 partials and one reduce launch: workspace = skinny_gemm_group_workspace_bytes(...) bytes, 256-byte aligned.
+ *
+ * row_halves = 1 (here, in skinny_gemm_f16, skinny_gemm_f16_partial and skinny_gemm_f16_grouped; honoured for M > 32 with
+ * the 128-column kernel): every tile and K-slice is worked on by TWO workgroups, one per half of the rows -- twice the
+ * workgroups without more partial planes (an unsplit launch then fills the chip with no partials and no reduce launch);
+ * both stream the W tile, side by side on one XCD so that HBM sees it once.  splits = 0 then chooses for twice the tiles;
+ * skinny_gemm_splits / *_workspace_bytes stay upper bounds.  Results are bit-identical to row_halves = 0 at the same
+ * split count (a row's sums never depend on other rows). */
 typedef struct {
     const void *x;     /* [M][ldx] binary16 */
     const void *w;     /* [n][ldw] binary16 */
@@ -237,9 +248,9 @@ typedef struct {
 } chirrup_gemm_problem;
 int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int K, int splits);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
-                          void *workspace, void *stream);
+                          int row_halves, void *workspace, void *stream);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
-                    void *Y, int ldy, int act, int splits, void *workspace, void *stream);
+                    void *Y, int ldy, int act, int splits, int row_halves, void *workspace, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight

@@ -244,3 +244,90 @@ def test_u8_tile_image_layout_gives_the_same_bits(oracle):
     assert torch.equal(untile_u8(flat, M, N), qT)
     for act in (0, 1):
         assert torch.equal(ops.mm8t_linear(x, qT, *args, act=act), ops.mm8t_linear(x, flat, *args, act=act, tiled=True))
+
+
+@pytest.mark.parametrize("M,N,K,bias,act", [(200, 16384, 4096, False, 1), (200, 4096, 4096, True, 0), (33, 132, 256, True, 1),
+                                            (47, 128, 128, False, 0), (256, 1000, 512, True, 1)])
+def test_row_halves_give_the_bits_of_the_whole_rows_launch(M, N, K, bias, act):
+    """row_halves: two workgroups per tile and K-slice, one per half of the rows.  A row's sums never depend on the other
+    rows, so at the same split count the results -- final values and partial planes -- are bit-identical."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda").half() if bias else None
+    for splits in (1, 2):
+        want = ops.skinny_linear(x, w, b, act=act, splits=splits)
+        assert torch.equal(ops.skinny_linear(x, w, b, act=act, splits=splits, row_halves=True), want)
+        if N % 128 == 0 and K % 64 == 0:
+            assert torch.equal(ops.skinny_linear(x, ops.tile_weight(w), b, act=act, splits=splits, row_halves=True), want)
+    pa, pb = torch.zeros(4, M, N, device="cuda"), torch.zeros(4, M, N, device="cuda")
+    a_, b_ = ops.skinny_linear_partial(x, w, 2, pa), ops.skinny_linear_partial(x, w, 2, pb, row_halves=True)
+    assert a_.shape == b_.shape and torch.equal(a_, b_) and float(pb[2:].abs().max()) == 0.0
+    # the library's own choice with row halves: a result of the same quality (a different split count, so not the same bits)
+    y = ops.skinny_linear(x, w, b, act=act, splits=0, row_halves=True)
+    want = _ref(x, w, b)
+    if act:
+        want = torch.relu(want.half().double()) ** 2
+    assert bool(((y.double() - want).abs() <= (4e-3 if act else 2e-3) * want.abs().clamp_min(1.0)).all())
+
+
+@pytest.mark.parametrize("splits", [0, 1, 2])
+def test_row_halves_of_a_grouped_launch(splits):
+    """The layer's R/K/V + LoRA down-projection launch (seven problems, tanh / sigmoid on two of them): unsplit, bias and
+    activations run in the GEMM epilogue (no partials, no reduce launch) -- the same arithmetic on the same binary32 sums
+    as the reduce kernel applies, so whole rows vs row halves and epilogue vs reduce kernel agree bit for bit."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(11)
+    M, K = 200, 4096
+    mixed = torch.randn(6, M, K, device="cuda").half()
+    rkv = [ops.tile_weight((torch.randn(4096, K, device="cuda") / K ** 0.5).half()) for _ in range(3)]
+    lora1 = (torch.randn(4, 512, K, device="cuda") / K ** 0.5).half()
+    bias = torch.randn(4096, device="cuda").half()
+    ranks, acts = [128, 128, 128, 512], [None, "tanh", None, "sigmoid"]
+
+    def run(s, halves):
+        out_rkv = torch.empty(3, M, 4096, device="cuda", dtype=torch.float16)
+        hid = torch.zeros(4, M, 512, device="cuda", dtype=torch.float16)
+        probs = [(mixed[j], rkv[j], out_rkv[j], bias if j == 1 else None, None) for j in range(3)]
+        probs += [(mixed[2 + j], lora1[j, :ranks[j]], hid[j, :, :ranks[j]], None, acts[j]) for j in range(4)]
+        ops.skinny_group(probs, splits=s, row_halves=halves)
+        return out_rkv, hid
+
+    if splits == 0:                 # the library's choice with halves is the unsplit launch (206 workgroups)
+        want, got = run(1, False), run(0, True)
+    else:
+        want, got = run(splits, False), run(splits, True)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    for j in range(4):
+        ref = (mixed[2 + j].double() @ lora1[j, :ranks[j]].double().t()).half().double()
+        ref = torch.tanh(ref) if acts[j] == "tanh" else (torch.sigmoid(ref) if acts[j] == "sigmoid" else ref)
+        assert bool(((got[1][j, :, :ranks[j]].double() - ref).abs() <= 2e-3 * ref.abs().clamp_min(1.0)).all()), j
+
+
+@pytest.mark.parametrize("M", [200, 33, 256, 17, 32])
+def test_row_halves_and_tiled_batch_give_the_same_bits(M):
+    """The LoRA up-projection launch: per-problem K, tile-image weights, and each problem as two workgroup sets over the
+    upper / lower half of the rows -- all bit-identical to the plain batched launch (row m's sums never depend on the
+    other rows)."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(M)
+    Z, N, K, ks = 4, 1024, 512, [128, 128, 64, 512]
+    x = torch.zeros(Z, M, K, device="cuda", dtype=torch.float16)
+    w = torch.zeros(Z, N, K, device="cuda", dtype=torch.float16)
+    for z, k in enumerate(ks):
+        x[z, :, :k] = torch.randn(M, k, device="cuda").half()
+        w[z, :, :k] = (torch.randn(N, k, device="cuda") / k ** 0.5).half()
+    b = torch.randn(Z, 1, N, device="cuda").half()
+    want = ops.skinny_bmm(x, w, b, splits=1, k_of=ks)
+    wt = ops.tile_weight_batch(w)
+    assert torch.equal(ops.skinny_bmm(x, w, b, splits=1, k_of=ks, m_split=True), want)
+    assert torch.equal(ops.skinny_bmm(x, wt, b, splits=1, k_of=ks), want)
+    assert torch.equal(ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, m_split=True), want)
+    assert torch.equal(ops.skinny_bmm(x[1:], wt[1:], b[1:], splits=1, k_of=ks[1:], m_split=True), want[1:])
+    out = torch.full((Z, M + 2, N), 3.0, device="cuda", dtype=torch.float16)       # nothing is written past row M
+    ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, m_split=True, out=out[:, :M])
+    assert torch.equal(out[:, :M], want) and bool((out[:, M:] == 3.0).all())
