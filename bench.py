@@ -220,22 +220,24 @@ def gemm_shape_timings(model, B):
         S = torch.zeros((B, 3), dtype=torch.float32, device=dev)
         xs2, S2 = torch.empty((B, 4 * C), dtype=torch.float16, device=dev), torch.empty((B, ops.mm8_row_parts(4 * C), 3), dtype=torch.float32, device=dev)
 
+        kview = [pk]
+
         def ffn_key8():
             for lw in lws:
-                ops.mm8t_gemm_partial(x_c, lw.f_K8.qT, 4 * C, gs["ffn_key"], pk, tiled=lw.f8_tiled)
+                kview[0] = ops.mm8t_gemm_partial(x_c, lw.f_K8.qT, 4 * C, gs["ffn_key"], pk, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
 
         def ffn_value8():
             for lw in lws:
-                ops.mm8t_gemm_partial(x_4c, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled)
+                ops.mm8t_gemm_partial(x_4c, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled, row_halves=rh["ffn_value"])
 
         def reduce_rows():
             for lw in lws:
-                ops.mm8_reduce_rows(pk, lw.f_K8.rx, lw.f_K8.mx, S, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs2, S2))
+                ops.mm8_reduce_rows(kview[0], lw.f_K8.rx, lw.f_K8.mx, S, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs2, S2))
 
         mm8_bytes = lambda n, m: n * m + 4 * (n + m) + 2 * B * (n + m)
         out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C), "u8 GEMM kernel (fp32 core partials; prologue in the LN kernel, corrections in mm8_reduce_rows)")
         out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "u8 GEMM kernel (fp32 core partials; prologue in mm8_reduce_rows, corrections in the next LN kernel)")
-        out["mm8_reduce_rows"] = (_replay_time(reduce_rows, L), pk.numel() * 4 + B * 4 * C * 2, "reduce + corrections + relu^2 of ffn.key and the prologue of ffn.value (bytes: partials in, xs out)")
+        out["mm8_reduce_rows"] = (_replay_time(reduce_rows, L), kview[0].numel() * 4 + B * 4 * C * 2, "reduce + corrections + relu^2 of ffn.key and the prologue of ffn.value (bytes: partials in, xs out)")
     if model._head_t is not None:
         out["head"] = (_replay_time(lambda: ops.skinny_linear(x_c, model._head_t, splits=1), 1), V * C * 2 + B * C * 2 + B * V * 2,
                        "unsplit GEMM kernel, fp16 epilogue")

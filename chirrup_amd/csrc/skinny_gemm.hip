@@ -550,7 +550,15 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const i
     }
     const int m = (int)(gi / (N_ / 4)), n = (int)(gi % (N_ / 4)) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < splits; k++) s += *reinterpret_cast<const f32x4 *>(part + ((int64_t)k * M + m) * N_ + n);
+    for (int k0 = 0; k0 < splits; k0 += 4) {           // four planes' loads in flight, added in plane order
+        f32x4 pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k0 + u < splits) pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(part + ((int64_t)(k0 + u) * M + m) * N_ + n));
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (k0 + u < splits) s += pv[u];
+    }
     f16x4 o, rxv = {}, mxv = {}, bv = {};
     if (mm8) rxv = *reinterpret_cast<const f16x4 *>(rx + n), mxv = *reinterpret_cast<const f16x4 *>(mx + n);
     else if (bias) bv = *reinterpret_cast<const f16x4 *>(bias + n);
@@ -1107,7 +1115,7 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
 // (rwkv7_add_ln_mix_mm8, mm8_reduce_rows): xs = the prologue's output [B][N_in] binary16 (B <= 256), partials receive the
 // fp32 core sums [splits][B][M_out].  Returns the split count used (> 0) or a negative error like skinny_gemm_f16_partial.
 extern "C" int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride,
-                                 int w_tiled, int splits, float *partials, void *stream) {
+                                 int w_tiled, int splits, int row_halves, float *partials, void *stream) {
     if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
     if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || xs_stride < N_in || w_stride < N_in ||
         (xs_stride & 7) || (w_stride & 15))
@@ -1115,11 +1123,13 @@ extern "C" int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int
     if (!xs || !wT || !partials) return CHIRRUP_E_NULL;
     if (mis16(xs) || mis16(wT) || mis16(partials)) return CHIRRUP_E_ALIGN;
     const int bn = choose_bn(M_out);
-    const int s = pick_splits(bn, M_out, N_in, splits);
-    const dim3 grid((M_out + bn - 1) / bn, s);
+    const bool halves = use_halves(row_halves, B, bn);
+    const int s = pick_splits(bn, M_out, N_in, splits, halves ? 2 : 1);
+    const dim3 grid((M_out + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    const int rc = launch_gemm<true, EPI_PARTIAL>(bn, (B + 15) / 16, grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
+    bs.m_split = halves ? 1 : 0;
+    const int rc = launch_gemm<true, EPI_PARTIAL>(bn, tiles_of(B, halves), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
                                                   static_cast<const f16 *>(xs), xs_stride, wT, w_stride, nullptr, M_out, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
 }

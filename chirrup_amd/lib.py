@@ -38,7 +38,7 @@ SIGNATURES = {
     "mm8_one": (_i, [_i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _f32p, _vp]),
     "rwkv7_add_ln_mix": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "rwkv7_add_ln_mix_mm8": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
-    "mm8t_gemm_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    "mm8t_gemm_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "mm8_reduce_rows": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mm8_row_parts": (_i, [_i]),
     "rwkv7_tmix_mid": (_i, [_i64, _i] + [_vp] * 9 + [_vp]),

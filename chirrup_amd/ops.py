@@ -569,7 +569,7 @@ def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None, 
     return out
 
 
-def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = False):
+def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = False, row_halves: bool = False):
     """The matrix product of mm8t_linear alone: xs [B<=256, N_in] fp16 (an mm8 prologue's output) against wT; fp32 core sums
     into `partials`, returned as the view [splits_used, B, M_out] (include/chirrup_amd.h: mm8t_gemm_partial)."""
     B, N = xs.shape
@@ -583,7 +583,7 @@ def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = F
     if partials.numel() < s_used * B * M_out:
         raise _lib.ChirrupAmdError("partials buffer too small")
     rc = _lib.load().mm8t_gemm_partial(B, N, M_out, xs.data_ptr(), xs.stride(0), wT.data_ptr(), N, int(tiled), splits,
-                                       partials.data_ptr(), _stream())
+                                       1 if row_halves else 0, partials.data_ptr(), _stream())
     if rc <= 0:
         raise _lib.ChirrupAmdError(f"mm8t_gemm_partial: {rc}")
     return partials.view(-1)[: rc * B * M_out].view(rc, B, M_out)

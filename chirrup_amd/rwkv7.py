@@ -531,9 +531,9 @@ class RWKV_x070:
                 x, x_alt = x_alt, x
                 commit_carry(prev)
             if q8:
-                kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled)
+                kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
                 ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))
-                dparts, delta = ops.mm8t_gemm_partial(xs_v, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled), None
+                dparts, delta = ops.mm8t_gemm_partial(xs_v, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled, row_halves=rh["ffn_value"]), None
                 dq = (lw.f_V8.rx, lw.f_V8.mx, S_v)
             elif self.ffn_dtype == torch.int8:      # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)

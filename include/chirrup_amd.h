@@ -314,7 +314,7 @@ int rwkv7_sample_topp(int n_rows, int V, const void *logits, const int32_t *rows
  */
 int mm8_row_parts(int M_out);
 int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride,
-                      int w_tiled, int splits, float *partials, void *stream);
+                      int w_tiled, int splits, int row_halves, float *partials, void *stream);
 int mm8_reduce_rows(int B, int M_out, int splits, const float *partials, const void *rx, const void *mx, const float *S,
                     int S_parts, int act, void *y, int y_stride, const void *ry2, const void *my2, void *xs2, float *S2,
                     void *stream);
