@@ -77,15 +77,21 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                                        const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
                                        float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
                                        int dsplits = 0, int64_t dsplit_stride = 0, const f16 *__restrict__ q_rx = nullptr,
-                                       const f16 *__restrict__ q_mx = nullptr, const float *__restrict__ q_S = nullptr) {
+                                       const f16 *__restrict__ q_mx = nullptr, const float *__restrict__ q_S = nullptr,
+                                       const int q_parts = 0, float *q_sh = nullptr) {
+    // q_S: this row's mm8 row sums [q_parts][3] in global memory; they are added up (one wave per sum) into q_sh[3] AFTER the
+    // loads of the row and of its first eight partial planes have been issued, so that their latency is not a stage of its own
     const int nchunk = C >> 3;
     float vals[kLnMaxChunks][8];
     float s = 0.f;
+    bool q_ready = false;
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
         const int c = threadIdx.x + q * kLnThreads;
-        if (c < nchunk) {
-            f16x8 xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
+        const bool in_row = c < nchunk;
+        {
+            f16x8 xv = {};
+            if (in_row) xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
             if (dpart) {            // delta = binary16(sum of split-K partials): the GEMM's reduce folded into this prologue
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 // up to 8 planes' loads are issued before the first add (one plane per trip costs one memory latency per
@@ -95,39 +101,53 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                     f32x4_t p[8][2];
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        if (s0 + u < dsplits) {
+                        if (in_row && s0 + u < dsplits) {
                             p[u][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8));
                             p[u][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8 + 4));
                         }
                     }
+                    if (q_S && !q_ready) {             // (uniform: every lane of the workgroup gets here, in_row or not)
+                        static_assert(kLnThreads >= 3 * 64, "one wave per sum");
+                        if (threadIdx.x < 3 * 64) {
+                            const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                            float tsum = 0.f;
+                            for (int pp = lane; pp < q_parts; pp += 64) tsum += q_S[pp * 3 + g];
+                            tsum = wave_sum(tsum);
+                            if (lane == 0) q_sh[g] = tsum;
+                        }
+                        __syncthreads();
+                        q_ready = true;
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
-                        if (s0 + u < dsplits) {
+                        if (in_row && s0 + u < dsplits) {
                             acc[0] += p[u][0].x; acc[1] += p[u][0].y; acc[2] += p[u][0].z; acc[3] += p[u][0].w;
                             acc[4] += p[u][1].x; acc[5] += p[u][1].y; acc[6] += p[u][1].z; acc[7] += p[u][1].w;
                         }
                     }
                 }
-                if (q_S) {            // the partials are the core of an mm8 product taken against 1024 + q (skinny_gemm.hip: cvt_u8x2):
+                if (q_S && in_row) {  // the partials are the core of an mm8 product taken against 1024 + q (skinny_gemm.hip: cvt_u8x2):
                                       // y = rx*(core - 1024*S0 + 0.5*S0) + S1 + mx*S2 (benchmark.py:167-179)
                     const f16x8 rxv = *reinterpret_cast<const f16x8 *>(q_rx + c * 8);
                     const f16x8 mxv = *reinterpret_cast<const f16x8 *>(q_mx + c * 8);
-                    const float s0 = q_S[0], s1 = q_S[1], s2 = q_S[2];
+                    const float s0 = q_sh[0], s1 = q_sh[1], s2 = q_sh[2];
 #pragma unroll
                     for (int e = 0; e < 8; e++) acc[e] = (float)rxv[e] * (acc[e] - 1023.5f * s0) + s1 + (float)mxv[e] * s2;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)h(acc[e]));
-            } else if (delta) {
+            } else if (delta && in_row) {
                 const f16x8 dv = *reinterpret_cast<const f16x8 *>(delta + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; e++) xv[e] = h((float)xv[e] + (float)dv[e]);
             }
-            if (x_out) *reinterpret_cast<f16x8 *>(x_out + c * 8) = xv;
+            if (in_row) {
+                if (x_out) *reinterpret_cast<f16x8 *>(x_out + c * 8) = xv;
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                vals[q][e] = (float)xv[e];
-                s += vals[q][e];
+                for (int e = 0; e < 8; e++) {
+                    vals[q][e] = (float)xv[e];
+                    s += vals[q][e];
+                }
             }
         }
     }
@@ -173,19 +193,10 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int64_t ro = (int64_t)row * C;
     float cur[kLnMaxChunks][8];
     const f16 *q_rx = static_cast<const f16 *>(fz.in_rx), *q_mx = static_cast<const f16 *>(fz.in_mx);
-    __shared__ float qsum[2][3];                      // mm8 row sums of this row and of its predecessor: the parts added up once
-    if (fz.in_S) {
-        if (threadIdx.x < 6) {
-            const int which = threadIdx.x / 3, j = threadIdx.x % 3, r_ = row - which;
-            float tsum = 0.f;
-            if (r_ >= 0)
-                for (int p = 0; p < fz.in_S_parts; p++) tsum += fz.in_S[((int64_t)r_ * fz.in_S_parts + p) * 3 + j];
-            qsum[which][j] = tsum;
-        }
-        __syncthreads();
-    }
+    __shared__ float qsum[2][3];                      // mm8 row sums of this row and of its predecessor (ln_row adds the parts up)
+    const float *q_row = fz.in_S ? fz.in_S + (int64_t)row * fz.in_S_parts * 3 : nullptr;
     ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
-           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, fz.in_S ? qsum[0] : nullptr);
+           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0]);
     if (NMIX == 0) {
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++) {
@@ -213,7 +224,8 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         }
     } else {
         ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red,
-               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride, q_rx, q_mx, fz.in_S ? qsum[1] : nullptr);
+               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row ? q_row - fz.in_S_parts * 3 : nullptr,
+               fz.in_S_parts, qsum[1]);
     }
     const f16 *p_ry = static_cast<const f16 *>(fz.out_ry), *p_my = static_cast<const f16 *>(fz.out_my);
     f16 *p_xs = static_cast<f16 *>(fz.out_xs);

@@ -56,7 +56,9 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 constexpr int kKB = 64;          // K-block
 constexpr int kTileRows = 128;   // rows of one tile image (skinny_tile_weight): both kernels stage whole 128-row tiles
 
-enum { EPI_F16 = 0, EPI_PARTIAL = 1 };
+// EPI_MM8 (uint8 weights, unsplit): the rank-1 corrections of the mm8 split form, relu^2 and the activation prologue of the
+// NEXT mm8 product in the GEMM's own epilogue (store_staged_mm8) -- no partials, no reduce launch
+enum { EPI_F16 = 0, EPI_PARTIAL = 1, EPI_MM8 = 2 };
 
 // two uint8 -> two binary16 values 1024 + b (exact): bytes b0,b1 -> halves 0x6400|b.  ONE v_perm per pair and no
 // subtraction: the matrix cores multiply by (1024 + q) and the constant is taken out again with the other rank-1 terms of
@@ -94,11 +96,21 @@ __device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &bat
 }
 
 // element strides between the problems of a batched launch (gridDim.z problems; 0s for a single GEMM)
+struct Mm8Epilogue {
+    const f16 *rx, *mx;          // [N] scales of this product's weights
+    const float *S;              // [M][S_parts][3] row sums of this product's prologue
+    const f16 *ry2, *my2;        // [N] scales of the next product (its K = this N); NULL: no prologue
+    f16 *xs2;                    // [M][N]
+    float *S2;                   // [M][S2_parts][3]: one partial row sum per 128-column tile
+    int S_parts, S2_parts, act;
+};
+
 struct BatchStrides {
     int64_t x, w, y, bias;
     int k[8];          // per-problem reduction length (<= K, multiple of 64) or 0 = K: zero-padded tails are not streamed
     int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
     int relu_sq;       // EPI_F16: y = relu(binary16(x.w + bias))^2 in the epilogue
+    Mm8Epilogue q8;    // EPI_MM8
     int m_split;       // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
@@ -144,6 +156,7 @@ struct Tile {
     float *part;
     int Np, ldy, ngroup, kslice, batch;
     int M;             // rows of x / y this workgroup works on (the launch's M, or its part under m_split)
+    int rows0;         // ... and its first row
     int act;           // EPI_F16: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (as skinny_reduce_kernel)
     bool w_tiled;
 };
@@ -158,6 +171,7 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
     t.M = M, t.act = bs.relu_sq ? 1 : 0;
     const int rows0 = half ? MT * 16 : 0;              // (m_split launches have M > 16 MT)
     if (bs.m_split) t.M = half ? M - MT * 16 : MT * 16;
+    t.rows0 = rows0;
     if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
         int b = 0;
         while (b + 1 < gt.used && t.ngroup >= gt.first[b + 1]) b++;
@@ -310,6 +324,26 @@ template <int EPI, int THREADS>
 __device__ __forceinline__ void store_staged(const float *stage, const int M, const int n_first, const Tile &t, const int kslice,
                                              const int plane_rows) {
     const int tid = threadIdx.x;
+    if (EPI == EPI_F16 && !(t.Np & 7) && !(t.ldy & 7) && !((reinterpret_cast<uintptr_t>(t.Y) | reinterpret_cast<uintptr_t>(t.bias)) & 15)) {
+        // 8 columns per lane, 16 lanes per row: 16-B stores (8-B stores run at 0.54-0.70x their rate, MI355X_MICROARCH.md)
+        const int c8 = tid & 15;
+        const int n = n_first + 8 * c8;
+        if (n >= t.Np) return;
+        f16x8 bv = {};
+        if (t.bias) bv = *reinterpret_cast<const f16x8 *>(t.bias + n);      // (bias + n: 16-B aligned for an aligned bias)
+        for (int m = tid >> 4; m < M; m += THREADS / 16) {
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 8 * c8);
+            const f32x4 vb = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 8 * c8 + 4);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float v = e < 4 ? va[e] : vb[e - 4];
+                o[e] = (f16)apply_act(t.bias ? v + (float)bv[e] : v, t.act);
+            }
+            *reinterpret_cast<f16x8 *>(t.Y + (int64_t)m * t.ldy + n) = o;
+        }
+        return;
+    }
     const int c4 = tid & 31;                           // 4 columns per lane, 32 lanes per row, THREADS/32 rows per pass
     const int n = n_first + 4 * c4;
     if (n >= t.Np) return;
@@ -322,6 +356,88 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
             *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
         } else {
             *reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * plane_rows + m) * t.Np + n) = v;
+        }
+    }
+}
+
+// EPI_MM8: `stage` holds the core sums sum_k xs*(1024 + q) of rows m x 128 columns.  Per element, the arithmetic of
+// mm8_reduce_rows_kernel: y = rx*(core - 1023.5*S0) + S1 + mx*S2 (benchmark.py:174-179 for kernels that multiply by 1024 + q),
+// relu(fp16(y))^2 (rwkv7.py:678), written to Y if given; and for the next mm8 product xs2 = fp16(y*ry2) and this tile's share
+// of its row sums {sum xs2, sum y*my2, sum y} -> S2[row][tile] (the consumer adds the tiles up in order).  A row of the
+// tile is handled by 16 lanes x 8 columns -- one DPP row, so the row sums are four row shifts at VALU rate, and the stores
+// are 16 B wide (measured per launch at 7.2B / bsz 200: partial epilogue 39.6 us; this with a 32-lane ds_bpermute butterfly
+// and 8-B stores 47.6, with DPP 44.5, with 16 lanes per row 42.0; the reduce launch it replaces: 7.8).
+// lane i of each 16-lane row receives v of lane i + n (0 past the row's end)
+__device__ __forceinline__ float dpp_row_shl(const float v, const int n) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (n) {
+        case 8: r = __builtin_amdgcn_update_dpp(0, x, 0x108, 0xf, 0xf, true); break;
+        case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0xf, true); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x102, 0xf, 0xf, true); break;
+        default: r = __builtin_amdgcn_update_dpp(0, x, 0x101, 0xf, 0xf, true); break;
+    }
+    return __builtin_bit_cast(float, r);
+}
+template <int THREADS>
+__device__ __forceinline__ void store_staged_mm8(const float *stage, const int M, const int n_first, const Tile &t, const Mm8Epilogue &e8) {
+    const int tid = threadIdx.x;
+    const int c8 = tid & 15;                           // 8 columns per lane: a row of the tile is one 16-lane DPP row
+    const int n = n_first + 8 * c8;
+    const bool live = n < t.Np;                        // (N % 4 == 0, and N % 8 == 0 is checked by the entry point)
+    f16x8 rxv = {}, mxv = {}, ryv = {}, myv = {};
+    if (live) {
+        rxv = *reinterpret_cast<const f16x8 *>(e8.rx + n), mxv = *reinterpret_cast<const f16x8 *>(e8.mx + n);
+        if (e8.xs2) ryv = *reinterpret_cast<const f16x8 *>(e8.ry2 + n), myv = *reinterpret_cast<const f16x8 *>(e8.my2 + n);
+    }
+    const int tile = n_first / kTileRows;
+    // this product's row sums, parts added up once, into the padding columns of the staged rows (a load per row inside
+    // the loop below is a memory latency per trip: +9 us per launch, measured)
+    for (int m = tid; m < M; m += THREADS) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int p = 0; p < e8.S_parts; p++) {
+            const float *sp = e8.S + ((int64_t)(t.rows0 + m) * e8.S_parts + p) * 3;
+            s0 += sp[0], s1 += sp[1], s2 += sp[2];
+        }
+        float *pad = const_cast<float *>(stage) + m * kLd + kTileRows;
+        pad[0] = s0, pad[1] = s1, pad[2] = s2;
+    }
+    __syncthreads();
+    for (int m = tid >> 4; m < M; m += THREADS / 16) {
+        const int row = t.rows0 + m;
+        const float s0 = stage[m * kLd + kTileRows], s1 = stage[m * kLd + kTileRows + 1], s2 = stage[m * kLd + kTileRows + 2];
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+        if (live) {
+            const f32x4 va = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 8 * c8);
+            const f32x4 vb = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 8 * c8 + 4);
+            f16x8 o, xs;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float y = (float)rxv[e] * ((e < 4 ? va[e] : vb[e - 4]) - (kU8Offset - 0.5f) * s0) + s1 + (float)mxv[e] * s2;
+                if (e8.act) {
+                    y = (float)(f16)y;
+                    y = y > 0.f ? y * y : 0.f;
+                }
+                o[e] = (f16)y;
+                xs[e] = (f16)((float)o[e] * (float)ryv[e]);
+                t0 += (float)xs[e];
+                t1 += (float)o[e] * (float)myv[e];
+                t2 += (float)o[e];
+            }
+            if (t.Y) *reinterpret_cast<f16x8 *>(t.Y + (int64_t)m * t.ldy + n) = o;      // (t.Y starts at this workgroup's first row)
+            if (e8.xs2) *reinterpret_cast<f16x8 *>(e8.xs2 + (int64_t)row * t.Np + n) = xs;
+        }
+        if (e8.xs2) {
+#pragma unroll
+            for (int sh = 8; sh >= 1; sh >>= 1) {      // 16 lanes -> their first lane by DPP row shifts (VALU rate; a
+                t0 += dpp_row_shl(t0, sh);              // ds_bpermute butterfly is dependent LDS round trips)
+                t1 += dpp_row_shl(t1, sh);
+                t2 += dpp_row_shl(t2, sh);
+            }
+            if (c8 == 0) {
+                float *dst = e8.S2 + ((int64_t)row * e8.S2_parts + tile) * 3;
+                dst[0] = t0, dst[1] = t1, dst[2] = t2;
+            }
         }
     }
 }
@@ -424,7 +540,8 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     __syncthreads();                                   // every compute wave is past its last fragment read
     if (wave_live) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
     __syncthreads();
-    store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
+    if constexpr (EPI == EPI_MM8) store_staged_mm8<256>(stg, t.M, n_base, t, bs.q8);
+    else store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -746,10 +863,15 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
     } while (0)
-#define GO(MTV)                                       \
-    do {                                              \
-        if (bn == 256) GO_K(wide_gemm_kernel, MTV);   \
-        else GO_K(ring_gemm_kernel, MTV);             \
+#define GO(MTV)                                                   \
+    do {                                                          \
+        if constexpr (EPI == EPI_MM8) {                           \
+            if (bn == 256) return CHIRRUP_E_UNSUPPORTED;          \
+            GO_K(ring_gemm_kernel, MTV);                          \
+        } else {                                                  \
+            if (bn == 256) GO_K(wide_gemm_kernel, MTV);           \
+            else GO_K(ring_gemm_kernel, MTV);                     \
+        }                                                         \
     } while (0)
     switch (MT) {                                      // 16-row tiles of x: M <= 256
         case 1: GO(1); break;
@@ -1132,6 +1254,38 @@ extern "C" int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int
     const int rc = launch_gemm<true, EPI_PARTIAL>(bn, tiles_of(B, halves), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
                                                   static_cast<const f16 *>(xs), xs_stride, wT, w_stride, nullptr, M_out, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
+}
+
+// mm8t_gemm_partial + mm8_reduce_rows in ONE launch, for products whose N gives an unsplit launch enough workgroups
+// (ffn.key: 128 tiles x 2 row halves): the core sums never leave the workgroup; corrections, relu^2 (act = 1), y (may be
+// NULL) and the next product's prologue (xs2, S2; may be NULL) come out of the GEMM epilogue.  S: [B][S_parts][3];
+// S2: [B][mm8_tile_parts(M_out)][3] -- one partial row sum per 128-column tile, which the consumer adds up in tile order
+// (rwkv7_add_ln_mix_mm8: in_S_parts; mm8_reduce_rows / this function: S_parts).  M_out < 32768 (the 128-column kernel).
+extern "C" int mm8_tile_parts(int M_out) { return M_out > 0 ? (M_out + kTileRows - 1) / kTileRows : 0; }
+
+extern "C" int mm8t_gemm_fused(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride, int w_tiled,
+                               const void *rx, const void *mx, const float *S, int S_parts, int act, void *y, int y_stride,
+                               const void *ry2, const void *my2, void *xs2, float *S2, int row_halves, void *stream) {
+    if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 7) || (N_in % kKB) || xs_stride < N_in || w_stride < N_in ||
+        (xs_stride & 7) || (w_stride & 15) || S_parts <= 0 || (y && (y_stride < M_out || (y_stride & 7))))
+        return CHIRRUP_E_SHAPE;
+    if (!xs || !wT || !rx || !mx || !S || (!y && !xs2)) return CHIRRUP_E_NULL;
+    if (xs2 && (!ry2 || !my2 || !S2)) return CHIRRUP_E_NULL;
+    if (mis16(xs) || mis16(wT) || mis16(y) || mis16(xs2) || mis16(rx) || mis16(mx) || mis16(ry2) || mis16(my2)) return CHIRRUP_E_ALIGN;
+    const int bn = choose_bn(M_out);
+    if (bn != 128) return CHIRRUP_E_UNSUPPORTED;
+    const bool halves = use_halves(row_halves, B, bn);
+    const dim3 grid((M_out + bn - 1) / bn, halves ? 2 : 1);
+    BatchStrides bs{};
+    bs.tiled = w_tiled ? 1 : 0;
+    bs.m_split = halves ? 1 : 0;
+    bs.q8.rx = static_cast<const f16 *>(rx), bs.q8.mx = static_cast<const f16 *>(mx), bs.q8.S = S, bs.q8.S_parts = S_parts;
+    bs.q8.ry2 = static_cast<const f16 *>(ry2), bs.q8.my2 = static_cast<const f16 *>(my2), bs.q8.xs2 = static_cast<f16 *>(xs2);
+    bs.q8.S2 = S2, bs.q8.S2_parts = mm8_tile_parts(M_out), bs.q8.act = act ? 1 : 0;
+    return launch_gemm<true, EPI_MM8>(bn, tiles_of(B, halves), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in,
+                                      static_cast<const f16 *>(xs), xs_stride, wT, w_stride, static_cast<f16 *>(y), y ? y_stride : M_out,
+                                      nullptr, nullptr, bs);
 }
 
 // Row-wise reduce of an mm8 product's partials with its rank-1 corrections (+ relu^2 when act = 1), writing y (may be

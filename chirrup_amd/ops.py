@@ -589,6 +589,37 @@ def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = F
     return partials.view(-1)[: rc * B * M_out].view(rc, B, M_out)
 
 
+def mm8_tile_parts(M: int) -> int:
+    """Partial row sums per row that mm8t_gemm_fused writes for an [.., M] product (one per 128-column tile)."""
+    return _lib.load().mm8_tile_parts(M)
+
+
+def mm8t_gemm_fused(xs, wT, M_out: int, rx, mx, S, act: int = 0, y=None, nxt=None, tiled: bool = False, row_halves: bool = True):
+    """mm8t_gemm_partial + mm8_reduce_rows in one unsplit launch (include/chirrup_amd.h): xs [B<=256, N_in] fp16 (an mm8
+    prologue's output) with its row sums S [B, 3] or [B, parts, 3]; writes y [B, M_out] if given and, with
+    nxt = (ry2, my2, xs2 [B, M_out], S2 [B, mm8_tile_parts(M_out), 3]), the prologue of the next mm8 product."""
+    B, N = xs.shape
+    if not xs.is_cuda or xs.dtype != torch.float16 or xs.stride(1) != 1:
+        raise _lib.ChirrupAmdError("xs: expected GPU fp16 with unit inner stride")
+    if not wT.is_cuda or wT.dtype != torch.uint8 or wT.numel() != M_out * N:
+        raise _lib.ChirrupAmdError("wT: expected GPU uint8 with M_out*N_in elements")
+    _chk16("rx", rx, M_out), _chk16("mx", mx, M_out)
+    _chk(S, "S", torch.float32)
+    if S.numel() % (B * 3):
+        raise _lib.ChirrupAmdError("S: expected fp32 [B, parts, 3]")
+    ry2 = my2 = xs2 = S2 = None
+    if nxt is not None:
+        ry2, my2, xs2, S2 = nxt
+        _chk16("ry2", ry2, M_out), _chk16("my2", my2, M_out), _chk16("xs2", xs2, B * M_out)
+        _chk(S2, "S2", torch.float32, (B, mm8_tile_parts(M_out), 3))
+    if y is not None:
+        _chk16("y", y, B * M_out)
+    rc = _lib.load().mm8t_gemm_fused(B, N, M_out, xs.data_ptr(), xs.stride(0), wT.data_ptr(), N, int(tiled), rx.data_ptr(), mx.data_ptr(),
+                                     S.data_ptr(), S.numel() // (B * 3), act, _ptr(y), M_out, _ptr(ry2), _ptr(my2), _ptr(xs2), _ptr(S2),
+                                     1 if row_halves else 0, _stream())
+    _lib.check(rc, "mm8t_gemm_fused")
+
+
 def mm8_row_parts(M: int) -> int:
     """Partial row sums per row that mm8_reduce_rows writes for an [.., M] product."""
     return _lib.load().mm8_row_parts(M)

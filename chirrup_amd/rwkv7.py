@@ -201,6 +201,7 @@ class RWKV_x070:
         self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
+        self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
         self.lora_up_m_split = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
@@ -436,8 +437,11 @@ class RWKV_x070:
         if q8:
             f32 = dict(dtype=torch.float32, device=dev)
             xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
-            xs_v, S_v = new(rows, 4 * C), torch.empty((rows, ops.mm8_row_parts(4 * C), 3), **f32)
-            pbuf_k = torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), rows, 4 * C), **f32)
+            # ffn.key's corrections + relu^2 + ffn.value's prologue in the key GEMM's epilogue (unsplit launch, row halves)
+            key_fused = self.mm8_fused_key and rows >= 128 and 4 * C < 32768
+            xs_v = new(rows, 4 * C)
+            S_v = torch.empty((rows, ops.mm8_tile_parts(4 * C) if key_fused else ops.mm8_row_parts(4 * C), 3), **f32)
+            pbuf_k = None if key_fused else torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), rows, 4 * C), **f32)
             pbuf = torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), **f32)
 
         def commit_carry(prev):
@@ -531,8 +535,12 @@ class RWKV_x070:
                 x, x_alt = x_alt, x
                 commit_carry(prev)
             if q8:
-                kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
-                ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))
+                if key_fused:
+                    ops.mm8t_gemm_fused(xs_k, lw.f_K8.qT, 4 * C, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v),
+                                        tiled=lw.f8_tiled)
+                else:
+                    kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
+                    ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))
                 dparts, delta = ops.mm8t_gemm_partial(xs_v, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled, row_halves=rh["ffn_value"]), None
                 dq = (lw.f_V8.rx, lw.f_V8.mx, S_v)
             elif self.ffn_dtype == torch.int8:      # mm8 on the matrix cores, relu^2 fused into the epilogue

@@ -145,7 +145,7 @@ typedef struct {
     const void *out_ry, *out_my; /* binary16 [C] */
     void *out_xs;                /* binary16 [B][T][C] */
     float *out_S;                /* [B*T][3] */
-    int in_S_parts;              /* 0 or 1: one sum per row; mm8_reduce_rows writes mm8_row_parts(C) of them */
+    int in_S_parts;              /* 0 or 1: one sum per row; mm8_reduce_rows writes mm8_row_parts(C) of them, mm8t_gemm_fused mm8_tile_parts(C) */
 } chirrup_mm8_fuse;
 int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                          const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
@@ -318,6 +318,14 @@ int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int xs_stride,
 int mm8_reduce_rows(int B, int M_out, int splits, const float *partials, const void *rx, const void *mx, const float *S,
                     int S_parts, int act, void *y, int y_stride, const void *ry2, const void *my2, void *xs2, float *S2,
                     void *stream);
+/* mm8t_gemm_partial + mm8_reduce_rows in ONE launch (unsplit; for products with enough 128-column tiles to fill the chip,
+ * e.g. ffn.key with row_halves): corrections, relu^2 (act = 1), y (may be NULL) and the next product's prologue (xs2 and S2
+ * [B][mm8_tile_parts(M_out)][3]; may be NULL) come out of the GEMM's own epilogue.  S: [B][S_parts][3].  B <= 256,
+ * M_out < 32768, M_out % 8 == 0, 16-byte aligned vectors.  Same element arithmetic as mm8_reduce_rows; the row sums S2 are split per 128-column tile. */
+int mm8_tile_parts(int M_out);
+int mm8t_gemm_fused(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride, int w_tiled,
+                    const void *rx, const void *mx, const float *S, int S_parts, int act, void *y, int y_stride,
+                    const void *ry2, const void *my2, void *xs2, float *S2, int row_halves, void *stream);
 
 #ifdef __cplusplus
 }

@@ -331,3 +331,46 @@ def test_row_halves_and_tiled_batch_give_the_same_bits(M):
     out = torch.full((Z, M + 2, N), 3.0, device="cuda", dtype=torch.float16)       # nothing is written past row M
     ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, m_split=True, out=out[:, :M])
     assert torch.equal(out[:, :M], want) and bool((out[:, M:] == 3.0).all())
+
+
+@pytest.mark.parametrize("B,K,N,halves,tiled", [(200, 1024, 4096, True, True), (200, 512, 1024, False, False), (33, 256, 384, True, False),
+                                                 (131, 256, 1000, True, False), (64, 128, 1004, True, False)])
+def test_mm8_corrections_in_the_gemm_epilogue(B, K, N, halves, tiled):
+    """mm8t_gemm_fused = mm8t_gemm_partial (unsplit) + mm8_reduce_rows in one launch: the same core sums and the same
+    element arithmetic, so y and the next product's xs come out bit-identical; the next product's row sums are split per
+    128-column tile instead of per 1024 columns (fp32 sums in another order)."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(B + K + N)
+    dev = "cuda"
+    x = torch.randn(B, K, device=dev).half()
+    q = torch.randint(0, 256, (N, K), device=dev, dtype=torch.uint8)
+    mx, rx = torch.randn(N, device=dev).half() * 0.01, torch.rand(N, device=dev).half() / 64
+    my, ry = torch.randn(K, device=dev).half() * 0.01, torch.rand(K, device=dev).half() / 16
+    my2, ry2 = torch.randn(N, device=dev).half() * 0.01, torch.rand(N, device=dev).half() / 16
+    xs = (x.float() * ry.float()).half()
+    S = torch.stack([xs.float().sum(1), (x.float() * my.float()).sum(1), x.float().sum(1)], 1).contiguous()
+    tiled = tiled and N % 128 == 0
+    qT = ops.tile_weight_u8(q) if tiled else q
+    if N % 8:
+        with pytest.raises(Exception):
+            ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=1, y=torch.empty(B, N, device=dev, dtype=torch.float16))
+        return
+    parts = ops.mm8t_gemm_partial(xs, qT, N, 1, torch.empty(1, B, N, device=dev), tiled=tiled)
+    y_a, xs_a = torch.empty(B, N, device=dev, dtype=torch.float16), torch.empty(B, N, device=dev, dtype=torch.float16)
+    S_a = torch.empty(B, ops.mm8_row_parts(N), 3, device=dev)
+    ops.mm8_reduce_rows(parts, rx, mx, S, act=1, y=y_a, nxt=(ry2, my2, xs_a, S_a))
+    y_b, xs_b = torch.zeros(B, N, device=dev, dtype=torch.float16), torch.zeros(B, N, device=dev, dtype=torch.float16)
+    S_b = torch.zeros(B, ops.mm8_tile_parts(N), 3, device=dev)
+    ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=1, y=y_b, nxt=(ry2, my2, xs_b, S_b), tiled=tiled, row_halves=halves)
+    assert torch.equal(y_a, y_b) and torch.equal(xs_a, xs_b)
+    want = torch.stack([xs_a.double().sum(1), (y_a.double() * my2.double()).sum(1), y_a.double().sum(1)], 1)
+    scale = torch.stack([xs_a.double().abs().sum(1), (y_a.double() * my2.double()).abs().sum(1), y_a.double().abs().sum(1)], 1) + 1e-30
+    assert float(((S_b.double().sum(1) - want).abs() / scale).max()) < 1e-5
+    assert float(((S_a.double().sum(1) - want).abs() / scale).max()) < 1e-5
+    # y only (no next product) and no relu^2
+    y_c = torch.empty(B, N, device=dev, dtype=torch.float16)
+    ops.mm8_reduce_rows(parts, rx, mx, S, act=0, y=y_c)
+    y_d = torch.empty(B, N, device=dev, dtype=torch.float16)
+    ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=0, y=y_d, tiled=tiled, row_halves=halves)
+    assert torch.equal(y_c, y_d)
