@@ -642,12 +642,16 @@ __global__ __launch_bounds__(512) void wide_gemm_kernel(
 //   mode 4 + p: the RWKV-7 LoRA hidden planes (v, w, a, g), first problem = plane p: tanh on w, sigmoid on g
 //               (rwkv7.py:626, :630), applied to the binary16-rounded sum like the reference's separate op
 // blockIdx.y = problem of a batched launch (partials [Z][splits][M][N], Y / bias advance by y_bs / bias_bs).
+// G: groups of 4 columns per lane -- 2 (one 16-B store per lane; 8-B stores run at 0.54-0.70x the rate) when every N, row
+// stride and pointer of the launch allows it (launch_reduce).
+template <int G>
 __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const int N, const int splits,
                                                             const float *__restrict__ part, const f16 *__restrict__ bias,
                                                             const f16 *__restrict__ rx, const f16 *__restrict__ mx,
                                                             const float *__restrict__ S, const int mode,
                                                             f16 *__restrict__ Y, int ldy, const int64_t y_bs = 0,
                                                             const int64_t bias_bs = 0, const GroupTable gt = GroupTable{}) {
+    constexpr int COLS = 4 * G;
     const int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int z = blockIdx.y;
     int N_ = N;
@@ -658,43 +662,64 @@ __global__ __launch_bounds__(256) void skinny_reduce_kernel(const int M, const i
         N_ = gt.N[z], ldy = gt.ldy[z], part = gt.part[z], Y = gt.Y[z], bias = gt.bias[z];
         act = gt.act[z];
     }
-    const int64_t total = (int64_t)M * N_ / 4;
+    const int64_t total = (int64_t)M * N_ / COLS;
     if (gi >= total) return;
     if (!gt.used) {
         part += (int64_t)z * splits * M * N;
         Y += z * y_bs;
         if (bias) bias += z * bias_bs;
     }
-    const int m = (int)(gi / (N_ / 4)), n = (int)(gi % (N_ / 4)) * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int m = (int)(gi / (N_ / COLS)), n = (int)(gi % (N_ / COLS)) * COLS;
+    f32x4 s[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) s[g] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < splits; k0 += 4) {           // four planes' loads in flight, added in plane order
-        f32x4 pv[4];
+        f32x4 pv[4][G];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (k0 + u < splits) pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(part + ((int64_t)(k0 + u) * M + m) * N_ + n));
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                if (k0 + u < splits)
+                    pv[u][g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(part + ((int64_t)(k0 + u) * M + m) * N_ + n + 4 * g));
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            if (k0 + u < splits) s += pv[u];
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                if (k0 + u < splits) s[g] += pv[u][g];
     }
-    f16x4 o, rxv = {}, mxv = {}, bv = {};
-    if (mm8) rxv = *reinterpret_cast<const f16x4 *>(rx + n), mxv = *reinterpret_cast<const f16x4 *>(mx + n);
-    else if (bias) bv = *reinterpret_cast<const f16x4 *>(bias + n);
+    f16 o[COLS];
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-        float v = s[e];
-        if (mm8) v = (float)rxv[e] * (v - (kU8Offset - 0.5f) * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mxv[e] * S[m * 3 + 2];
-        else if (bias) v += (float)bv[e];
-        if (act == 1) {
-            v = (float)(f16)v;                       // relu(fp16(y))**2, rwkv7.py:678
-            v = v > 0.f ? v * v : 0.f;
-        } else if (act == 2) {
-            v = tanhf((float)(f16)v);
-        } else if (act == 3) {
-            v = 1.f / (1.f + __expf(-(float)(f16)v));
+    for (int g = 0; g < G; g++) {
+        f16x4 rxv = {}, mxv = {}, bv = {};
+        if (mm8) rxv = *reinterpret_cast<const f16x4 *>(rx + n + 4 * g), mxv = *reinterpret_cast<const f16x4 *>(mx + n + 4 * g);
+        else if (bias) bv = *reinterpret_cast<const f16x4 *>(bias + n + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            float v = s[g][e];
+            if (mm8) v = (float)rxv[e] * (v - (kU8Offset - 0.5f) * S[m * 3 + 0]) + S[m * 3 + 1] + (float)mxv[e] * S[m * 3 + 2];
+            else if (bias) v += (float)bv[e];
+            o[4 * g + e] = (f16)apply_act(v, act);
         }
-        o[e] = (f16)v;
     }
-    *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = o;
+    if constexpr (G == 2) {
+        *reinterpret_cast<f16x8 *>(Y + (int64_t)m * ldy + n) = (f16x8){o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+    } else {
+        *reinterpret_cast<f16x4 *>(Y + (int64_t)m * ldy + n) = (f16x4){o[0], o[1], o[2], o[3]};
+    }
+}
+
+// wide: every problem has N % 8 == 0, ldy % 8 == 0 and a 16-byte aligned Y (callers check)
+int launch_reduce(bool wide, unsigned zdim, hipStream_t st, int M, int N, int s, const float *part, const f16 *bias, const f16 *rx,
+                  const f16 *mx, const float *S, int mode, f16 *Y, int ldy, int64_t y_bs = 0, int64_t bias_bs = 0,
+                  const GroupTable &gt = GroupTable{}) {
+    const int64_t total = (int64_t)M * N / (wide ? 8 : 4);
+    const dim3 grid((unsigned)((total + 255) / 256), zdim);
+    if (wide) hipLaunchKernelGGL(skinny_reduce_kernel<2>, grid, dim3(256), 0, st, M, N, s, part, bias, rx, mx, S, mode, Y, ldy, y_bs, bias_bs, gt);
+    else hipLaunchKernelGGL(skinny_reduce_kernel<1>, grid, dim3(256), 0, st, M, N, s, part, bias, rx, mx, S, mode, Y, ldy, y_bs, bias_bs, gt);
+    return (int)hipGetLastError();
+}
+inline bool wide_ok(int N, int ldy, const void *Y, int64_t y_bs = 0) {
+    return !(N & 7) && !(ldy & 7) && !(reinterpret_cast<uintptr_t>(Y) & 15) && !(y_bs & 7);
 }
 
 // mm8 activation prologue: xs = fp16(x * ry), S[m] = {sum xs, sum x*my, sum x}   (benchmark.py:167-173)
@@ -999,10 +1024,8 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
                                                    (const f16 *)bias, (float *)workspace, bs);
     if (rc) return rc;
     if (partial) {
-        const int64_t total = (int64_t)M * N / 4;
-        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, M, N, s,
-                           (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr, act ? 1 : 0, (f16 *)Y, ldy);
-        rc = (int)hipGetLastError();
+        rc = launch_reduce(wide_ok(N, ldy, Y), 1, st, M, N, s, (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr,
+                           act ? 1 : 0, (f16 *)Y, ldy);
     }
     return rc;
 }
@@ -1063,11 +1086,8 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
                                                    (const f16 *)bias, (float *)workspace, bs);
     if (rc) return rc;
     if (partial) {
-        const int64_t total = (int64_t)M * N / 4;
-        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), Z), dim3(256), 0, st, M, N, s,
-                           (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr, act, (f16 *)Y, ldy, y_bs,
-                           bias_bs);
-        rc = (int)hipGetLastError();
+        rc = launch_reduce(wide_ok(N, ldy, Y, y_bs), Z, st, M, N, s, (const float *)workspace, (const f16 *)bias, nullptr, nullptr, nullptr,
+                           act, (f16 *)Y, ldy, y_bs, bias_bs);
     }
     return rc;
 }
@@ -1147,11 +1167,9 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
     int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
                                              nullptr, gt.part[0], bs, gt);
     if (rc) return rc;
-    const int64_t total = (int64_t)M * max_n / 4;
-    hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256), count), dim3(256), 0, st, M, max_n, s,
-                       (const float *)nullptr, (const f16 *)nullptr, nullptr, nullptr, nullptr, 0, (f16 *)nullptr, 0, (int64_t)0,
-                       (int64_t)0, gt);
-    return (int)hipGetLastError();
+    bool wide = true;
+    for (int i = 0; i < count; i++) wide = wide && wide_ok(gt.N[i], gt.ldy[i], gt.Y[i]);
+    return launch_reduce(wide, count, st, M, max_n, s, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, gt);
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
@@ -1224,10 +1242,8 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
         int rc = launch_gemm<true, EPI_PARTIAL>(bnc, MT, grid, st, bn, M_out, N_in, N_in / s, xs, N_in, wT, w_stride, yb, y_stride,
                                                 nullptr, part, bs);
         if (rc) return rc;
-        const int64_t total = (int64_t)bn * M_out / 4;
-        hipLaunchKernelGGL(skinny_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bn, M_out, s, part,
-                           nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2, yb, y_stride);
-        rc = (int)hipGetLastError();
+        rc = launch_reduce(wide_ok(M_out, y_stride, yb), 1, st, bn, M_out, s, part, nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2,
+                           yb, y_stride);
         if (rc) return rc;
     }
     return 0;

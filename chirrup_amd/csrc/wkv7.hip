@@ -94,7 +94,14 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 
 // MODE 0: the operator of the reference (inputs a = -kk, b = kk*a given).  MODE 1: fused time-mix core:
 // k, v are the RAW projections, a_/b_ are unused, y_ receives (group_norm(y) + bonus*v) * g.
-template <int MODE>
+// DECAYED (MODE 0 only): w_ already holds w~ (wkv7_decay_kernel below) -- for chunks of many tokens everything that does
+// not depend on the state is computed by row-parallel kernels (rwkv7_tmix_mid, wkv7_decay, rwkv7_tmix_post) and the
+// sequential loop keeps only the recurrence.  The loop is VALU-issue bound (one wave per head, ~530 instructions per
+// token of which 320 are the packed-half multiplies and adds that the one-rounding-per-operation contract keeps
+// apart): the two binary64 exp2 per channel and token of decay_term and the gating / group-norm arithmetic of MODE 1 are
+// a third of it, and no load latency is exposed (eight tokens of prefetch instead of one: slower, the code no longer
+// fits the instruction cache -- profiles/r02_prefill_B25_T100.txt).
+template <int MODE, bool DECAYED = false>
 __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const int T, const int C, const int H, f16 *__restrict__ state, const int64_t slot_stride,
     const int32_t *__restrict__ slot_idx, const f16 *__restrict__ r_, const f16 *__restrict__ w_,
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
             }
         }
         vec[0 * 64 + lane] = r_cur;
-        vec[1 * 64 + lane] = decay_term(wj, dither);
+        vec[1 * 64 + lane] = DECAYED ? wj : decay_term(wj, dither);
         vec[2 * 64 + lane] = k_in;
         vec[3 * 64 + lane] = a_in;
         vec[4 * 64 + lane] = b_in;
@@ -283,6 +290,49 @@ extern "C" int WKV7_CAT(wkv7_fwd_seq, WKV7_ENTRY_SUFFIX)(int B, int T, int C, in
 }
 
 #ifndef WKV7_VARIANT_BUILD
+namespace {
+// w~[b][t][c] = decay_term(w[b][t][c], dither(elapsed_t[b] + t)): the per-token decay of the WKV7 update (.cu:23, :59),
+// the same device function the scan kernel evaluates in its loop, over all rows at once.
+__global__ __launch_bounds__(256) void wkv7_decay_kernel(const int64_t nchunks, const int T, const int C, const f16 *__restrict__ w,
+                                                         const int32_t *__restrict__ elapsed_t, f16 *__restrict__ w_out) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nchunks) return;
+    const int64_t row = g * 8 / C;
+    const int bb = (int)(row / T), t = (int)(row - (int64_t)bb * T);
+    const float dither = kTwoToNeg41 * (float)(int32_t)(kRo1 * (uint32_t)(elapsed_t[bb] + t));
+    const f16x8 wv = *reinterpret_cast<const f16x8 *>(w + g * 8);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = decay_term(wv[e], dither);
+    *reinterpret_cast<f16x8 *>(w_out + g * 8) = o;
+}
+}  // namespace
+
+extern "C" int wkv7_decay(int B, int T, int C, const void *w, const int32_t *elapsed_t, void *w_out, void *stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 7)) return CHIRRUP_E_SHAPE;
+    if (!w || !elapsed_t || !w_out) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(w_out) & 15)) return CHIRRUP_E_ALIGN;
+    const int64_t nchunks = (int64_t)B * T * C / 8;
+    hipLaunchKernelGGL(wkv7_decay_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       nchunks, T, C, static_cast<const f16 *>(w), elapsed_t, static_cast<f16 *>(w_out));
+    return (int)hipGetLastError();
+}
+
+// wkv7_fwd_seq with the decay already applied to w (w = wkv7_decay(w_raw)): bit-identical results, the T loop without
+// the transcendental work.
+extern "C" int wkv7_fwd_seq_decayed(int B, int T, int C, int H, void *state, const void *r, const void *w_decayed, const void *k,
+                                    const void *v, const void *a, const void *b, void *y, const int32_t *elapsed_t,
+                                    const int32_t *slot_idx, int64_t slot_stride, void *stream) {
+    const int rc = check_args(B, T, C, H, state, r, w_decayed, k, v, a, b, y, elapsed_t, slot_stride);
+    if (rc != CHIRRUP_OK) return rc;
+    if (slot_stride == 0) slot_stride = (int64_t)H * 4096;
+    hipLaunchKernelGGL((wkv7_seq_kernel<0, true>), dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
+                       static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
+                       static_cast<const f16 *>(w_decayed), static_cast<const f16 *>(k), static_cast<const f16 *>(v),
+                       static_cast<const f16 *>(a), static_cast<const f16 *>(b), static_cast<f16 *>(y), elapsed_t, TmixArgs{});
+    return (int)hipGetLastError();
+}
+
 // Fused time-mix core: gating (rwkv7.py:629-637) + WKV7 (:645) + group-norm / bonus / gate (:647-649).
 extern "C" int rwkv7_tmix_wkv7_fused(int B, int T, int C, int H, void *state, const void *r, const void *w,
                                      const void *k, const void *v, const void *a_pre, const void *vg_pre,

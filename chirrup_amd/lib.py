@@ -26,6 +26,8 @@ SIGNATURES = {
     "chirrup_abi_version": (_i, []),
     "chirrup_target_arch": (ctypes.c_char_p, []),
     "wkv7_fwd_seq": (_i, [_i, _i, _i, _i] + [_vp] * 10 + [_i64, _vp]),
+    "wkv7_fwd_seq_decayed": (_i, [_i, _i, _i, _i] + [_vp] * 10 + [_i64, _vp]),
+    "wkv7_decay": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "wkv7_fwd_one": (_i, [_i, _i, _i] + [_vp] * 10 + [_i64, _vp]),
     "spmv_fp16_workspace_bytes": (_i64, [_i, _i]),
     "spmv_fp16": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -40,12 +40,15 @@ def _chk(t: torch.Tensor, name: str, dtype, shape=None):
 
 
 def forward_seq(B: int, T: int, C: int, H: int, state: torch.Tensor, r, w, k, v, a, b, y,
-                elapsed_t: torch.Tensor, slot_idx: Optional[torch.Tensor] = None) -> None:
+                elapsed_t: torch.Tensor, slot_idx: Optional[torch.Tensor] = None, split_decay: bool = False) -> None:
     """rwkv7_state_fwd_fp16::forward_seq (Albatross/rwkv7.py:151). Mutates ``state`` and ``y``.
 
     state: fp16 [n_slots, H, 64, 64] (n_slots == B unless slot_idx is given); may be a
     contiguous view into a larger pool.  r,w,k,v,a,b,y: fp16 with B*T*C elements.
     elapsed_t: int32 [B].
+    split_decay: the per-token decay w~ is computed for all rows by one row-parallel launch in front of the scan
+    (wkv7_decay + wkv7_fwd_seq_decayed, include/chirrup_amd.h): the same bits, a much shorter sequential loop -- for
+    chunks of many tokens.
     """
     L = _lib.load()
     if H * HEAD_SIZE != C:
@@ -67,6 +70,15 @@ def forward_seq(B: int, T: int, C: int, H: int, state: torch.Tensor, r, w, k, v,
         si_ptr = slot_idx.data_ptr()
     elif n_slots != B:
         raise _lib.ChirrupAmdError(f"state has {n_slots} slots for batch {B} and no slot_idx")
+    if split_decay:
+        if not w.is_contiguous():
+            raise _lib.ChirrupAmdError("w: expected contiguous [B,T,C]")
+        wd = torch.empty_like(w)
+        _lib.check(L.wkv7_decay(B, T, C, w.data_ptr(), elapsed_t.data_ptr(), wd.data_ptr(), _stream()), "wkv7_decay")
+        rc = L.wkv7_fwd_seq_decayed(B, T, C, H, state.data_ptr(), r.data_ptr(), wd.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                    a.data_ptr(), b.data_ptr(), y.data_ptr(), elapsed_t.data_ptr(), si_ptr, 0, _stream())
+        _lib.check(rc, "wkv7_fwd_seq_decayed")
+        return
     rc = L.wkv7_fwd_seq(B, T, C, H, state.data_ptr(), r.data_ptr(), w.data_ptr(), k.data_ptr(), v.data_ptr(),
                         a.data_ptr(), b.data_ptr(), y.data_ptr(), elapsed_t.data_ptr(), si_ptr, 0, _stream())
     _lib.check(rc, "wkv7_fwd_seq")

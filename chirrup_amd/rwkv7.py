@@ -197,6 +197,8 @@ class RWKV_x070:
         self._side = torch.cuda.Stream(device=self.device) if (fused and self.device.type == "cuda") else None
         self.overlap_lora = True
         self.fuse_tmix_core = wkv_impl is None           # one kernel for gating + WKV7 + output chain
+        self.split_tmix_min_T = 32                       # ... up to this many tokens per sequence; longer chunks: row-parallel gating / decay /
+                                                         # group-norm launches around a recurrence-only scan (0: never)
         self.skinny_ffn_value = True                     # hand-written ring GEMM for ffn.value at decode batch sizes
         self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
@@ -411,7 +413,10 @@ class RWKV_x070:
         x = x.contiguous()
         new = lambda *shape: torch.empty(shape, dtype=DTYPE, device=dev)
         mixed, kin, o_in = new(6, rows, C), new(1, B, T, C), new(B, T, C)
-        if not self.fuse_tmix_core:
+        # chunks of many tokens: the state-independent arithmetic (gating, decay, group norm) in row-parallel launches
+        # around a scan that keeps only the recurrence; single tokens: everything in one kernel (k', v', -kk, kk*a, y stay on chip)
+        fuse_core = self.fuse_tmix_core and not (self.split_tmix_min_T and T >= self.split_tmix_min_T)
+        if not fuse_core:
             y, neg_kk, kka = new(B, T, C), new(B, T, C), new(B, T, C)
         carry = (new(B, C) if slot_idx is None else torch.empty_like(s0[0][0])) if T > 1 else None
         # T > 1: the LN kernel's row t re-reads x[t-1] (+ delta[t-1]) for the token shift, so the updated residual
@@ -508,7 +513,7 @@ class RWKV_x070:
             w, a_pre, g = (up[j - p0].view(B, T, C) for j in (1, 2, 3))
             if not s1[i].is_contiguous():
                 raise ops._lib.ChirrupAmdError("state[1][layer] view must be contiguous (slice the batch dim only)")
-            if self.fuse_tmix_core:
+            if fuse_core:
                 # gating + WKV7 + group-norm/bonus/gate in ONE kernel; k', v', -kk, kk*a, y never reach HBM
                 ops.tmix_wkv7_fused(B, T, C, H, s1[i], r, w, k, v, a_pre, vg_pre, v_first if i > 0 else None, g, lw.k_k,
                                     lw.k_a, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in, elapsed, slot_idx)
@@ -518,7 +523,10 @@ class RWKV_x070:
                 ops.tmix_mid(rows, C, k, v, a_pre, vg_pre, v_first if i > 0 else None, lw.k_k, lw.k_a, neg_kk, kka)
                 if i == 0:
                     v_first = v
-                self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
+                if self._wkv is ops.forward_seq:
+                    ops.forward_seq(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx, split_decay=T >= 4)
+                else:
+                    self._wkv(B, T, C, H, s1[i], r, w, k, v, neg_kk, kka, y, elapsed, slot_idx)
                 ops.tmix_post(rows, C, y, r, k, v, g, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in)
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]

@@ -56,6 +56,13 @@ int wkv7_fwd_seq(int B, int T, int C, int H, void *state, const void *r, const v
 int wkv7_fwd_one(int B, int C, int H, void *state, const void *r, const void *w, const void *k,
                  const void *v, const void *a, const void *b, void *y, const int32_t *elapsed_t,
                  const int32_t *slot_idx, int64_t slot_stride, void *stream);
+/* The state-independent part of the update taken out of the sequential loop, for chunks of many tokens: wkv7_decay computes
+ * w~ = exp(-e^-0.5 * sigmoid(w)) - 1 + dither(elapsed_t[b] + t) for every row at once (cu:23, :59; w, w_out binary16
+ * [B][T][C]); wkv7_fwd_seq_decayed is wkv7_fwd_seq given w~ instead of w.  Together bit-identical to wkv7_fwd_seq. */
+int wkv7_decay(int B, int T, int C, const void *w, const int32_t *elapsed_t, void *w_out, void *stream);
+int wkv7_fwd_seq_decayed(int B, int T, int C, int H, void *state, const void *r, const void *w_decayed, const void *k,
+                         const void *v, const void *a, const void *b, void *y, const int32_t *elapsed_t,
+                         const int32_t *slot_idx, int64_t slot_stride, void *stream);
 
 /*
  * Sparse binary16 vector x matrix: out[c] += sum_{d : vec[d] != 0} vec[d] * mat[d][c].

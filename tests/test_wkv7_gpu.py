@@ -11,7 +11,7 @@ from util import bits, wkv7_inputs
 pytestmark = pytest.mark.gpu
 
 
-def _run_gpu(state, r, w, k, v, a, b, et, slot_idx=None, one=False):
+def _run_gpu(state, r, w, k, v, a, b, et, slot_idx=None, one=False, split_decay=False):
     from chirrup_amd import ops
 
     dev = "cuda:0"
@@ -25,7 +25,7 @@ def _run_gpu(state, r, w, k, v, a, b, et, slot_idx=None, one=False):
         assert T == 1
         ops.forward_one(B, C, C // 64, tS, tr, tw, tk, tv, ta, tb, y, te, si)
     else:
-        ops.forward_seq(B, T, C, C // 64, tS, tr, tw, tk, tv, ta, tb, y, te, si)
+        ops.forward_seq(B, T, C, C // 64, tS, tr, tw, tk, tv, ta, tb, y, te, si, split_decay=split_decay)
     torch.cuda.synchronize()
     return y.cpu().numpy(), tS.cpu().numpy()
 
@@ -52,6 +52,20 @@ def test_wkv7_bit_exact_vs_oracle(oracle, B, T, C, elapsed):
     ns = int((bits(S) != bits(S_ref)).sum())
     assert ny == 0 and ns == 0, f"{ny} y / {ns} state elements differ; max |dS| = " \
         f"{np.abs(S.astype(np.float32) - S_ref.astype(np.float32)).max()}"
+
+
+@pytest.mark.parametrize("B,T,C,elapsed", [(7, 100, 256, "big"), (3, 5, 128, "arange"), (25, 40, 512, "big"), (2, 1, 64, "zero")])
+def test_wkv7_decay_outside_the_scan_is_bit_exact(oracle, B, T, C, elapsed):
+    """Chunked prefill: the per-token decay w~ (two exp2 per channel, dither of elapsed + t) computed for all rows by one
+    row-parallel launch and the scan given w~ -- the same device function on the same inputs, so state and y keep the
+    oracle's bits; slot indirection included."""
+    n_slots = B + 3
+    state, r, w, k, v, a, b, et = wkv7_inputs(B, T, C, seed=B * 1000 + T * 10 + C // 64 + 1, elapsed=elapsed, n_slots=n_slots)
+    idx = np.random.default_rng(B + T).permutation(n_slots)[:B].astype(np.int32)
+    S_ref = state.copy()
+    y_ref = oracle.wkv7_seq(S_ref, r, w, k, v, a, b, et, slot_idx=idx)
+    y, S = _run_gpu(state, r, w, k, v, a, b, et, slot_idx=idx, split_decay=True)
+    assert np.array_equal(bits(y), bits(y_ref)) and np.array_equal(bits(S), bits(S_ref))
 
 
 def test_wkv7_slot_pool_indirection(oracle):
