@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
+    p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
     p.add_argument("--lora-m-split", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
@@ -213,7 +214,7 @@ def gemm_shape_timings(model, B):
             for lw in lws:
                 ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf, row_halves=rh["ffn_value"])
 
-        out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "GEMM kernel + reduce with relu^2")
+        out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "unsplit GEMM kernel, two row halves per tile, relu^2 in the epilogue" if (rh["ffn_key"] and B >= 128 and not gs["ffn_key"]) else "GEMM kernel + reduce with relu^2")
         out["ffn_value"] = (_replay_time(ffn_value, L), 4 * C * C * 2 + B * 4 * C * 2 + B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
     elif lws[0].f_K8 is not None:
         pk = torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), B, 4 * C), dtype=torch.float32, device=dev)
@@ -221,10 +222,15 @@ def gemm_shape_timings(model, B):
         xs2, S2 = torch.empty((B, 4 * C), dtype=torch.float16, device=dev), torch.empty((B, ops.mm8_row_parts(4 * C), 3), dtype=torch.float32, device=dev)
 
         kview = [pk]
+        fused_key = model.mm8_fused_key and B >= 128
+        S2t = torch.empty((B, ops.mm8_tile_parts(4 * C), 3), dtype=torch.float32, device=dev)
 
         def ffn_key8():
             for lw in lws:
-                kview[0] = ops.mm8t_gemm_partial(x_c, lw.f_K8.qT, 4 * C, gs["ffn_key"], pk, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
+                if fused_key:
+                    ops.mm8t_gemm_fused(x_c, lw.f_K8.qT, 4 * C, lw.f_K8.rx, lw.f_K8.mx, S, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs2, S2t), tiled=lw.f8_tiled)
+                else:
+                    kview[0] = ops.mm8t_gemm_partial(x_c, lw.f_K8.qT, 4 * C, gs["ffn_key"], pk, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
 
         def ffn_value8():
             for lw in lws:
@@ -235,9 +241,13 @@ def gemm_shape_timings(model, B):
                 ops.mm8_reduce_rows(kview[0], lw.f_K8.rx, lw.f_K8.mx, S, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs2, S2))
 
         mm8_bytes = lambda n, m: n * m + 4 * (n + m) + 2 * B * (n + m)
-        out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C), "u8 GEMM kernel (fp32 core partials; prologue in the LN kernel, corrections in mm8_reduce_rows)")
-        out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "u8 GEMM kernel (fp32 core partials; prologue in mm8_reduce_rows, corrections in the next LN kernel)")
-        out["mm8_reduce_rows"] = (_replay_time(reduce_rows, L), kview[0].numel() * 4 + B * 4 * C * 2, "reduce + corrections + relu^2 of ffn.key and the prologue of ffn.value (bytes: partials in, xs out)")
+        out["ffn_key_u8"] = (_replay_time(ffn_key8, L), mm8_bytes(C, 4 * C),
+                             "u8 GEMM kernel, unsplit, two row halves per tile; corrections, relu^2 and ffn.value's prologue in its epilogue (prologue of its own in the LN kernel)"
+                             if fused_key else "u8 GEMM kernel (fp32 core partials; prologue in the LN kernel, corrections in mm8_reduce_rows)")
+        out["ffn_value_u8"] = (_replay_time(ffn_value8, L), mm8_bytes(4 * C, C), "u8 GEMM kernel (fp32 core partials; prologue in ffn.key's epilogue, corrections in the next LN kernel)"
+                               if fused_key else "u8 GEMM kernel (fp32 core partials; prologue in mm8_reduce_rows, corrections in the next LN kernel)")
+        if not fused_key:
+            out["mm8_reduce_rows"] = (_replay_time(reduce_rows, L), kview[0].numel() * 4 + B * 4 * C * 2, "reduce + corrections + relu^2 of ffn.key and the prologue of ffn.value (bytes: partials in, xs out)")
     if model._head_t is not None:
         out["head"] = (_replay_time(lambda: ops.skinny_linear(x_c, model._head_t, splits=1), 1), V * C * 2 + B * C * 2 + B * V * 2,
                        "unsplit GEMM kernel, fp16 epilogue")
@@ -246,10 +256,11 @@ def gemm_shape_timings(model, B):
 
 def gemm_roofline_object(timings, L):
     traffic = {}
-    f = os.path.join(ROOT, "profiles", "r02_gemm_pmc_traffic.json")
-    if os.path.exists(f):
-        for shape, rec in json.load(open(f))["shapes"].items():
-            traffic[shape.replace(".", "_")] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+    for name in ("r02_gemm_pmc_traffic.json", "r02b_gemm_pmc_traffic.json"):       # r02b: the shapes that changed since (row halves)
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            for shape, rec in json.load(open(f))["shapes"].items():
+                traffic[shape.replace(".", "_")] = rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
     shapes = {}
     for name, (ms, nbytes, what) in timings.items():
         ach = nbytes / (ms * 1e-3) / 1e9
@@ -257,7 +268,7 @@ def gemm_roofline_object(timings, L):
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name), "what": what,
                         "launches_per_step": 1 if name == "head" else L}
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "bytes": "algorithmic: weight + x + y (fp16); split-K partials are not counted; traffic = HBM read + written bytes incl. partials (profiles/r02_gemm_pmc_traffic.json)",
+            "bytes": "algorithmic: weight + x + y (fp16); split-K partials are not counted; traffic = HBM read + written bytes incl. partials (profiles/r02_gemm_pmc_traffic.json, r02b_...)",
             "shapes": shapes}
 
 
@@ -475,6 +486,8 @@ def main():
         model.gemm_splits.update(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (int(v) for v in a.splits.split(","))))
     if a.row_halves is not None:
         model.gemm_row_halves = dict(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (bool(int(v)) for v in a.row_halves.split(","))))
+    if a.split_tmix_min_t is not None:
+        model.split_tmix_min_T = a.split_tmix_min_t
     if a.lora_m_split is not None:
         model.lora_up_m_split = bool(a.lora_m_split)
     if a.skinny_key is not None:
@@ -510,6 +523,7 @@ def main():
         del state
         m8 = build_model(a.model, dev, fused=True, mm8=True, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
         m8.gemm_splits.update(model.gemm_splits)
+        m8.gemm_row_halves = dict(model.gemm_row_halves)
         dt8, st8 = timed_decode(m8, B, a, dev, rank, steps=max(8, a.steps // 2))
         t8 = gemm_shape_timings(m8, B)
         mm8_obj = {"ms_per_step": round(dt8 / max(8, a.steps // 2) * 1e3, 4), "dtype": "f16 activations, u8 ffn.key / ffn.value weights (w8a16)",

@@ -2,7 +2,8 @@
 `rocprofv3 --pmc ...` can attribute counters to it.  The calls are the model's own (tile-image weights, same splits).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_gemm.py ffn.value
-shapes: ffn.key | ffn.value | att.output | rkv_lora (the grouped launch) | head | ffn.key.u8 | ffn.value.u8
+shapes: ffn.key | ffn.value | att.output | rkv_lora (the grouped launch) | lora_up | head | ffn.key.u8 | ffn.value.u8
+(ffn.key, att.output and lora_up as shipped: two workgroups per tile over the two halves of the rows)
 """
 import os
 import sys
@@ -24,11 +25,11 @@ if shape == "ffn.value":
 elif shape == "ffn.key":
     Ws = [ops.tile_weight(rnd(4 * C, C)) for _ in range(NW)]
     x = torch.randn(M, C, device=dev).half()
-    run = lambda W: ops.skinny_linear(x, W, act=1, splits=2)
+    run = lambda W: ops.skinny_linear(x, W, act=1, splits=0, row_halves=True)          # unsplit, 128 tiles x 2 row halves
 elif shape == "att.output":
     Ws = [ops.tile_weight(rnd(C, C)) for _ in range(NW * 2)]
-    x, part = torch.randn(M, C, device=dev).half(), torch.empty(4, M, C, device=dev, dtype=torch.float32)
-    run = lambda W: ops.skinny_linear_partial(x, W, 4, part)
+    x, part = torch.randn(M, C, device=dev).half(), torch.empty(8, M, C, device=dev, dtype=torch.float32)
+    run = lambda W: ops.skinny_linear_partial(x, W, 0, part, row_halves=True)           # split 4 x 32 tiles x 2 row halves
 elif shape == "head":
     Ws = [ops.tile_weight(rnd(65536, C)) for _ in range(2)]
     x = torch.randn(M, C, device=dev).half()
@@ -45,6 +46,11 @@ elif shape == "rkv_lora":
             kj = (ranks[j] + 63) // 64 * 64
             probs.append((mixed[2 + j], W[1][j][:kj], hid[j, :, :kj], None, "tanh" if j == 1 else None))
         ops.skinny_group(probs, splits=2)
+elif shape == "lora_up":
+    ranks = [128, 128, 128, 512]
+    Ws = [ops.tile_weight_batch((torch.randn(4, C, 512, device=dev) / 512 ** 0.5).half()) for _ in range(NW * 2)]
+    hid, lb = torch.randn(4, M, 512, device=dev).half(), torch.randn(4, 1, C, device=dev).half()
+    run = lambda W: ops.skinny_bmm(hid, W, lb, splits=1, k_of=ranks, m_split=True)
 elif shape in ("ffn.key.u8", "ffn.value.u8"):
     n, k = (4 * C, C) if shape == "ffn.key.u8" else (C, 4 * C)
     Ws = [ops.tile_weight_u8(torch.randint(0, 256, (n, k), device=dev, dtype=torch.uint8)) for _ in range(NW)]
