@@ -215,9 +215,10 @@ class RWKV_x070:
         # K-split factors of the hand-written GEMMs (0 = the library's choice); tuning knobs for tools/ and bench.py
         self.gemm_splits = {"rkv": 0, "att_out": 0, "ffn_key": 0, "ffn_value": 0}
         # ... and two workgroups per tile, one per half of the rows (include/chirrup_amd.h: row_halves), for >= 128 rows:
-        # att.output then needs 4 partial planes instead of 8, ffn.key none (no reduce launch).  A/B at 7.2B / bsz 200 on one
-        # box (profiles/r02_gemm_experiments.txt section 10): step 7.27 -> 7.09 ms; R/K/V and ffn.value lose with it.
-        self.gemm_row_halves = {"rkv": False, "att_out": True, "ffn_key": True, "ffn_value": False}
+        # att.output then needs 4 partial planes instead of 8, ffn.key and the R/K/V + LoRA-down group none (no reduce launches).
+        # A/B at 7.2B / bsz 200 on one box (profiles/r02_gemm_experiments.txt section 10): step 7.27 -> 7.09 ms with att.output and
+        # ffn.key, another -0.04 ms with R/K/V once the epilogue stored 16 bytes per lane; ffn.value loses with it.
+        self.gemm_row_halves = {"rkv": True, "att_out": True, "ffn_key": True, "ffn_value": False}
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it

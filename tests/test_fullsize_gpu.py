@@ -182,3 +182,32 @@ def test_prefill_chunk_equals_tokens_fed_one_at_a_time_at_production_width(big):
     e_lg = rel_linf(lg_a.cpu().numpy(), lg_b.cpu().numpy())
     print(f"chunk vs token-by-token: wkv {e_wkv:.2e} shift {e_shift:.2e} logits {e_lg:.2e}")
     assert e_wkv <= 4e-3 and e_shift <= 4e-3 and e_lg <= 4e-3      # measured 1.6e-3 / 1.2e-3 / 1.3e-3
+
+
+@pytest.mark.parametrize("B", [130, 256])
+def test_row_halves_at_other_batch_sizes_match_the_whole_row_launches(big, B):
+    """The GEMM configuration of the decode step (two workgroups per tile over the two halves of the rows for R/K/V + LoRA-down,
+    att.output, ffn.key and the LoRA up-projections; unsplit launches with the activation in the epilogue) against the
+    whole-row launches with their reduce kernels, at batch sizes whose halves are unequal (130 = 80 + 50 rows) or full
+    (256 = 128 + 128): other split counts, so rounding-level differences only."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+
+    zd, _ = big
+    sub = {k: v for k, v in zd.items() if not (k.startswith("blocks.") and int(k.split(".")[1]) >= 2)}
+    model = RWKV_x070(_args(), state_dict=sub, device="cuda:0")
+    toks = np.random.default_rng(B).integers(1, V, size=(B, 1)).tolist()
+    st0 = _random_state(2, B, 11)
+
+    def run():
+        st = [torch.from_numpy(a.copy()).cuda() for a in st0]
+        lg = model.forward_seq_batch_seperate(toks, st)
+        return lg.float().cpu().numpy(), [s.cpu().numpy() for s in st]
+
+    lg_a, st_a = run()
+    assert any(model.gemm_row_halves.values()) and model.lora_up_m_split
+    model.gemm_row_halves = dict.fromkeys(model.gemm_row_halves, False)
+    model.lora_up_m_split = False
+    lg_b, st_b = run()
+    e = (rel_linf(lg_a, lg_b), rel_linf(st_a[1], st_b[1]), rel_linf(st_a[0], st_b[0]))
+    print("row halves vs whole rows:", e)
+    assert max(e) <= 2e-3 and st_a[2].tolist() == st_b[2].tolist()
