@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
-    p.add_argument("--lora-m-split", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
+    p.add_argument("--lora-row-halves", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
     p.add_argument("--group-tmix", type=int, default=None, help="1/0: R/K/V + LoRA down-projections as one grouped launch, A/B only")
@@ -194,7 +194,7 @@ def gemm_shape_timings(model, B):
 
     def lora_up():
         for lw in lws:
-            ops.skinny_bmm(hid, lw.lora2_t if lw.lora2_t is not None else lw.lora2, lw.lbias, splits=1, k_of=ranks, m_split=model.lora_up_m_split)
+            ops.skinny_bmm(hid, lw.lora2_t if lw.lora2_t is not None else lw.lora2, lw.lbias, splits=1, k_of=ranks, row_halves=model.lora_up_row_halves)
 
     out["lora_up"] = (_replay_time(lora_up, L), n_dn * C * 2 + B * n_dn * 2 + 4 * B * C * 2, "batched launch of the 4 LoRA up-projections, bias in the epilogue")
     x_c, x_4c = rnd(B, C), rnd(B, 4 * C)
@@ -488,8 +488,8 @@ def main():
         model.gemm_row_halves = dict(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (bool(int(v)) for v in a.row_halves.split(","))))
     if a.split_tmix_min_t is not None:
         model.split_tmix_min_T = a.split_tmix_min_t
-    if a.lora_m_split is not None:
-        model.lora_up_m_split = bool(a.lora_m_split)
+    if a.lora_row_halves is not None:
+        model.lora_up_row_halves = bool(a.lora_row_halves)
     if a.skinny_key is not None:
         model.skinny_ffn_key = bool(a.skinny_key)
     if a.skinny_rkv is not None:

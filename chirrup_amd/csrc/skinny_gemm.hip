@@ -5,34 +5,35 @@
 //
 // Why hand-written: at M = 200 the library GEMMs (hipBLASLt through torch) stream weights at 1.4-2.8 TB/s and every
 // projection is its own launch.  Here the batch is small enough that ONE workgroup holds all M rows of x for its K-block
-// in LDS, and independent problems share a launch.  What bounds these kernels is the operand INGEST of a CU, not HBM
-// (profiles/r02_gemm_pmc_traffic.json: HBM bytes = algorithmic bytes, x re-reads are L2 hits): a CU takes in ~28 B/clk
-// through LDS-DMA whatever the source, and every workgroup needs all M rows of x beside its W tile.
+// in LDS, and independent problems share a launch.  HBM traffic equals the algorithmic bytes (profiles/r02_gemm_pmc_traffic
+// .json, r02b_...: the x re-reads are L2 hits); what bounds the launches is POWER -- the chip runs the main loop at
+// 1.36 GHz, 2.1 GHz with either the MFMAs or the loads alone (profiles/r02_gemm_experiments.txt) -- so the levers are
+// doing less work and spending less time outside the main loop, not overlapping more.
 //
-// Both kernels: a 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA (global_load_lds_dwordx4) into rings --
+// Both kernels: a 64-wide K-block of BOTH operands goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) into rings --
 // x image MT*16 rows x 128 B, W image BN rows x 128 B (u8: 64 B), XOR-swizzled on the SOURCE address so that the
 // ds_read_b128 of the MFMA fragments are conflict-free.  No load of the main loop has a register destination, so hand-
 // placed `s_waitcnt vmcnt(n)` + one raw `s_barrier` per K-block keep whole stages in flight across the barrier.
 // A compute wave owns 32 rows of W as two 16-row tiles: v_mfma_f32_16x16x32_f16 with A = W tile (16 n x 32 k), B = x^T
 // (32 k x 16 m); one x fragment feeds two MFMAs, one W fragment MT = ceil(M/16) of them (u8 -> f16 by v_perm in
-// registers).  16-row tiles because these launches are POWER-bound (profiles/r02_gemm_experiments.txt: the chip runs
-// the main loop at 1.36 GHz, 2.1 GHz with either the MFMAs or the loads alone): M = 200 pads to 208 rows instead of 224
-// (-7 % MFMAs, fragment reads and x bytes), and the 16x16x32 shape delivers more flops per joule than 32x32x16
-// (MI355X_MICROARCH.md, DVFS give-back item 7).
+// registers).  16-row tiles: M = 200 pads to 208 rows instead of 224 (-7 % MFMAs, fragment reads and x bytes), and the
+// 16x16x32 shape delivers more flops per joule than 32x32x16 (MI355X_MICROARCH.md, DVFS give-back item 7).
 //
-// wide_gemm_kernel (BN = 256): 8 compute waves, two per SIMD; waves 0-3 also issue the x loads of the NEXT K-block
-//     (L2-resident, 2 slots) at the start of an iteration, waves 4-7 the W loads two K-blocks ahead (HBM, `nt`, 3 slots)
-//     in the MIDDLE of theirs -- a wave is blocked while its LDS-DMA instructions issue, and this way its SIMD partner
-//     has MFMAs to run meanwhile; vmcnt retires in order per wave, so the split also keeps the x wait from waiting on W.
-//     Per W byte a workgroup ingests 0.875 B of x (224 x 128 B per 256 x 128 B) instead of 1.75 B at BN = 128.
-// ring_gemm_kernel (BN = 128): 4 compute + 4 dedicated loader waves, one 3-slot ring for both operands (round 1's
-//     kernel).  Kept for the narrow problems (LoRA ranks, N < 256) and as the A/B partner (CHIRRUP_GEMM_BN=128|256).
+// ring_gemm_kernel (BN = 128; every GEMM of a layer): 4 compute + 4 dedicated loader waves, one ring for both operands, as
+//     deep as 160 KiB of LDS allows (3 slots at 13 x tiles, 5 at 7: ring_depth).
+// wide_gemm_kernel (BN = 256; the head, N >= 32768): 8 compute waves, two per SIMD; waves 0-3 also issue the x loads of the
+//     NEXT K-block (L2-resident, 2 slots) at the start of an iteration, waves 4-7 the W loads two K-blocks ahead (HBM,
+//     `nt`, 3 slots) in the MIDDLE of theirs -- a wave is blocked while its LDS-DMA instructions issue, and this way its
+//     SIMD partner has MFMAs to run meanwhile.  Per W byte a workgroup ingests 0.875 B of x instead of 1.75 B at BN = 128.
 //
 // Common: split-K over blockIdx.y with binary32 partials, reduced by skinny_reduce_kernel (bias, relu^2, tanh / sigmoid
 // of the LoRA planes, or the mm8 rank-1 corrections of scripts/test_mm8/benchmark.py:167-179) or by the NEXT layer-norm
-// kernel (rwkv7_add_ln_mix, delta_partials); batched (gridDim.z problems at uniform strides, optional per-problem K) and
-// grouped launches (per-problem operands, N and output stride; blockIdx.x runs over an exact tile list -- an empty
-// workgroup would still have to be given its LDS before it could leave); workgroup -> tile order is XCD-aware.
+// kernel (rwkv7_add_ln_mix, delta_partials); unsplit launches apply bias / activation (EPI_F16) or the whole mm8
+// epilogue incl. the next product's prologue (EPI_MM8) themselves; ROW HALVES (BatchStrides::row_halves): two workgroups
+// per tile and K-slice, one per half of the rows -- twice the workgroups without more partial planes, W streamed by both
+// from one XCD's L2; batched (gridDim.z problems at uniform strides, optional per-problem K) and grouped launches (per-
+// problem operands, N and output stride; blockIdx.x runs over an exact tile list); workgroup -> tile order is XCD-aware
+// and grids are padded to a multiple of 8 workgroups so that it stays so.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -78,7 +79,7 @@ __device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
 // Workgroup -> (N-group, K-slice).  Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its
 // own L2: give XCD j a contiguous run of the K-slice-major tile order, so the x K-slice a workgroup re-reads is shared
 // by its L2 neighbours (ffn.value at bsz 200: x is 6.5 MB, a K-slice 0.8 MB; the L2 is 4 MB).
-// halves = 2 (row halves, BatchStrides::m_split): the two workgroups of a tile's K-slice are neighbours in that order --
+// halves = 2 (row halves, BatchStrides::row_halves): the two workgroups of a tile's K-slice are neighbours in that order --
 // on the same XCD when the grid divides by 8 and dispatched together, so the W tile both stream is fetched from HBM once.
 __device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch, int &half, const int halves) {
     const int G = gridDim.x, GS = G * (gridDim.y / halves), total = G * gridDim.y * gridDim.z;
@@ -111,7 +112,7 @@ struct BatchStrides {
     int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
     int relu_sq;       // EPI_F16: y = relu(binary16(x.w + bias))^2 in the epilogue
     Mm8Epilogue q8;    // EPI_MM8
-    int m_split;       // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
+    int row_halves;    // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
                        //    ring is deeper
@@ -155,7 +156,7 @@ struct Tile {
     const f16 *bias;
     float *part;
     int Np, ldy, ngroup, kslice, batch;
-    int M;             // rows of x / y this workgroup works on (the launch's M, or its part under m_split)
+    int M;             // rows of x / y this workgroup works on (the launch's M, or its part under row_halves)
     int rows0;         // ... and its first row
     int act;           // EPI_F16: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (as skinny_reduce_kernel)
     bool w_tiled;
@@ -166,11 +167,11 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
                                              float *part, const int M, const int ldx, const BatchStrides &bs, const GroupTable &gt) {
     Tile t;
     int half;
-    tile_of_block(t.ngroup, t.kslice, t.batch, half, bs.m_split ? 2 : 1);
+    tile_of_block(t.ngroup, t.kslice, t.batch, half, bs.row_halves ? 2 : 1);
     t.X = X, t.W = Wv, t.Y = Y, t.bias = bias, t.part = part, t.Np = N, t.ldy = ldy, t.w_tiled = bs.tiled != 0;
     t.M = M, t.act = bs.relu_sq ? 1 : 0;
-    const int rows0 = half ? MT * 16 : 0;              // (m_split launches have M > 16 MT)
-    if (bs.m_split) t.M = half ? M - MT * 16 : MT * 16;
+    const int rows0 = half ? MT * 16 : 0;              // (row_halves launches have M > 16 MT)
+    if (bs.row_halves) t.M = half ? M - MT * 16 : MT * 16;
     t.rows0 = rows0;
     if (gt.used) {                                     // per-problem operands; blockIdx.x runs over all problems' N-groups
         int b = 0;
@@ -186,7 +187,7 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
         t.W = static_cast<const unsigned char *>(Wv) + t.batch * bs.w * (W8 ? 1 : 2);
         if (Y) t.Y += t.batch * bs.y;
         if (bias) t.bias += t.batch * bs.bias;
-        if (part) t.part += (int64_t)t.batch * (gridDim.y >> (bs.m_split ? 1 : 0)) * M * N;
+        if (part) t.part += (int64_t)t.batch * (gridDim.y >> (bs.row_halves ? 1 : 0)) * M * N;
     }
     t.X += (int64_t)rows0 * ldx;
     if (t.Y) t.Y += (int64_t)rows0 * t.ldy;
@@ -1016,7 +1017,7 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     bs.relu_sq = (!partial && act == 1) ? 1 : 0;
     int rc = partial ? launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                        (const f16 *)bias, (float *)workspace, bs)
@@ -1048,11 +1049,11 @@ extern "C" int skinny_gemm_f16_batched(int Z, int M, int N, int K, const void *X
 // of X[z] and W[z] (k_of[z] <= K, a multiple of 64; k_of == NULL: K for all).  For operands that are zero-padded to a
 // common K (RWKV-7's LoRA ranks: 96 / 128 / 128 / 480 packed as 512) the padding is then never read.  Z <= 8, and
 // splits must be 1 when k_of is given.  w_tiled: every W[z] is a tile image of the [N][K] matrix (skinny_tile_weight).
-// m_split = 1 (unsplit launches without activation only): each problem runs as two sets of workgroups over the upper and
+// row_halves = 1 (unsplit launches without activation only): each problem runs as two sets of workgroups over the upper and
 // lower half of the rows -- twice the workgroups and a deeper operand ring for problems with few K-blocks.
 extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_of, const void *X, int ldx, int64_t x_bs,
                                        const void *W, int64_t ldw, int64_t w_bs, int w_tiled, const void *bias, int64_t bias_bs,
-                                       void *Y, int ldy, int64_t y_bs, int act, int splits, int m_split, void *workspace,
+                                       void *Y, int ldy, int64_t y_bs, int act, int splits, int row_halves, void *workspace,
                                        void *stream) {
     if (Z <= 0 || Z > 65535 || M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N ||
         (ldx & 7) || (ldw & 7) || (ldy & 3) || (x_bs & 7) || (w_bs & 7) || (y_bs & 3) || act < 0 || act > 7 || act == 2 || act == 3)
@@ -1065,14 +1066,14 @@ extern "C" int skinny_gemm_f16_grouped(int Z, int M, int N, int K, const int *k_
     const bool partial = s > 1 || act != 0;
     if (partial && !workspace) return CHIRRUP_E_NULL;
     if (w_tiled && (N % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
-    const bool halves = !partial && use_halves(m_split, M, bn);
+    const bool halves = !partial && use_halves(row_halves, M, bn);
     const int MT = tiles_of(M, halves);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s, Z);
     BatchStrides bs{};
     bs.x = x_bs, bs.w = w_bs, bs.y = y_bs, bs.bias = bias_bs;
     bs.tiled = w_tiled ? 1 : 0;
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     if (k_of) {
         if (Z > 8 || splits != 1) return CHIRRUP_E_UNSUPPORTED;
         for (int z = 0; z < Z; z++) {
@@ -1160,7 +1161,7 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(gt.first[count], halves ? 2 * s : s, 1);
     BatchStrides bs{};
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     if (s == 1)
         return launch_gemm<false, EPI_F16>(bn, MT, grid, st, M, max_n, K, K, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0], nullptr,
                                            nullptr, bs, gt);
@@ -1186,7 +1187,7 @@ extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int l
     const dim3 grid((N + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     const int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, static_cast<hipStream_t>(stream), M, N, K, K / s, (const f16 *)X, ldx,
                                                    W, ldw, nullptr, N, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
@@ -1266,7 +1267,7 @@ extern "C" int mm8t_gemm_partial(int B, int N_in, int M_out, const void *xs, int
     const dim3 grid((M_out + bn - 1) / bn, halves ? 2 * s : s);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     const int rc = launch_gemm<true, EPI_PARTIAL>(bn, tiles_of(B, halves), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
                                                   static_cast<const f16 *>(xs), xs_stride, wT, w_stride, nullptr, M_out, nullptr, partials, bs);
     return rc ? -1000 - rc : s;
@@ -1295,7 +1296,7 @@ extern "C" int mm8t_gemm_fused(int B, int N_in, int M_out, const void *xs, int x
     const dim3 grid((M_out + bn - 1) / bn, halves ? 2 : 1);
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
-    bs.m_split = halves ? 1 : 0;
+    bs.row_halves = halves ? 1 : 0;
     bs.q8.rx = static_cast<const f16 *>(rx), bs.q8.mx = static_cast<const f16 *>(mx), bs.q8.S = S, bs.q8.S_parts = S_parts;
     bs.q8.ry2 = static_cast<const f16 *>(ry2), bs.q8.my2 = static_cast<const f16 *>(my2), bs.q8.xs2 = static_cast<f16 *>(xs2);
     bs.q8.S2 = S2, bs.q8.S2_parts = mm8_tile_parts(M_out), bs.q8.act = act ? 1 : 0;

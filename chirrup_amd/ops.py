@@ -439,11 +439,11 @@ class TiledWeightBatch:
         return TiledWeightBatch(d, d.shape[0], self.shape[1], self.shape[2])
 
 
-def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_of=None, m_split: bool = False):
+def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_of=None, row_halves: bool = False):
     """Batched skinny_linear in one launch: x [Z, M<=256, K], weight [Z, N, K] (K % 64 == 0; or a TiledWeightBatch),
     bias [Z, 1, N] or [Z, N] -> [Z, M, N].  act as skinny_gemm_f16_batched (include/chirrup_amd.h): 1 relu^2, 4 + p LoRA
     planes.  k_of: optional per-problem reduction lengths (multiples of 64, <= K; needs splits=1): zero-padded tails of
-    x / weight beyond k_of[z] are not read.  m_split: two workgroup sets per problem over the two halves of the rows
+    x / weight beyond k_of[z] are not read.  row_halves: two workgroup sets per problem over the two halves of the rows
     (unsplit, no activation: problems of few K-blocks)."""
     w_tiled = isinstance(weight, TiledWeightBatch)
     if w_tiled:
@@ -476,7 +476,7 @@ def skinny_bmm(x, weight, bias=None, act: int = 0, splits: int = 0, out=None, k_
         karr = (ctypes.c_int * Z)(*[int(k) for k in k_of])
     rc = L.skinny_gemm_f16_grouped(Z, M, N, K, karr, x.data_ptr(), x.stride(1), x.stride(0), weight.data_ptr(), wstrides[1],
                                    wstrides[0], 1 if w_tiled else 0, _ptr(bias), bias_bs, out.data_ptr(), out.stride(1),
-                                   out.stride(0), act, splits, 1 if m_split else 0, ws.data_ptr(), _stream())
+                                   out.stride(0), act, splits, 1 if row_halves else 0, ws.data_ptr(), _stream())
     _lib.check(rc, "skinny_gemm_f16_grouped")
     return out
 

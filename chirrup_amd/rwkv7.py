@@ -204,7 +204,7 @@ class RWKV_x070:
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
-        self.lora_up_m_split = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
+        self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
@@ -487,7 +487,7 @@ class RWKV_x070:
                 ops.skinny_group(probs, splits=gs["rkv"], row_halves=rh["rkv"])
                 # the up-projections: 4 x C/128 tiles of 2..8 K-blocks -- two row halves per tile fill the chip
                 up = ops.skinny_bmm(hid[: 4 - p0], (lw.lora2_t if lw.lora2_t is not None else lw.lora2)[p0:], lw.lbias[p0:], splits=1,
-                                    k_of=lw.lora_k[p0:], m_split=self.lora_up_m_split)
+                                    k_of=lw.lora_k[p0:], row_halves=self.lora_up_row_halves)
                 side = None
             if side is not None:
                 side.wait_stream(main)

@@ -204,9 +204,9 @@ def test_row_halves_at_other_batch_sizes_match_the_whole_row_launches(big, B):
         return lg.float().cpu().numpy(), [s.cpu().numpy() for s in st]
 
     lg_a, st_a = run()
-    assert any(model.gemm_row_halves.values()) and model.lora_up_m_split
+    assert any(model.gemm_row_halves.values()) and model.lora_up_row_halves
     model.gemm_row_halves = dict.fromkeys(model.gemm_row_halves, False)
-    model.lora_up_m_split = False
+    model.lora_up_row_halves = False
     lg_b, st_b = run()
     e = (rel_linf(lg_a, lg_b), rel_linf(st_a[1], st_b[1]), rel_linf(st_a[0], st_b[0]))
     print("row halves vs whole rows:", e)

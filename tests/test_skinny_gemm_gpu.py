@@ -324,12 +324,12 @@ def test_row_halves_and_tiled_batch_give_the_same_bits(M):
     b = torch.randn(Z, 1, N, device="cuda").half()
     want = ops.skinny_bmm(x, w, b, splits=1, k_of=ks)
     wt = ops.tile_weight_batch(w)
-    assert torch.equal(ops.skinny_bmm(x, w, b, splits=1, k_of=ks, m_split=True), want)
+    assert torch.equal(ops.skinny_bmm(x, w, b, splits=1, k_of=ks, row_halves=True), want)
     assert torch.equal(ops.skinny_bmm(x, wt, b, splits=1, k_of=ks), want)
-    assert torch.equal(ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, m_split=True), want)
-    assert torch.equal(ops.skinny_bmm(x[1:], wt[1:], b[1:], splits=1, k_of=ks[1:], m_split=True), want[1:])
+    assert torch.equal(ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, row_halves=True), want)
+    assert torch.equal(ops.skinny_bmm(x[1:], wt[1:], b[1:], splits=1, k_of=ks[1:], row_halves=True), want[1:])
     out = torch.full((Z, M + 2, N), 3.0, device="cuda", dtype=torch.float16)       # nothing is written past row M
-    ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, m_split=True, out=out[:, :M])
+    ops.skinny_bmm(x, wt, b, splits=1, k_of=ks, row_halves=True, out=out[:, :M])
     assert torch.equal(out[:, :M], want) and bool((out[:, M:] == 3.0).all())
 
 

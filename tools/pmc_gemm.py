@@ -50,7 +50,7 @@ elif shape == "lora_up":
     ranks = [128, 128, 128, 512]
     Ws = [ops.tile_weight_batch((torch.randn(4, C, 512, device=dev) / 512 ** 0.5).half()) for _ in range(NW * 2)]
     hid, lb = torch.randn(4, M, 512, device=dev).half(), torch.randn(4, 1, C, device=dev).half()
-    run = lambda W: ops.skinny_bmm(hid, W, lb, splits=1, k_of=ranks, m_split=True)
+    run = lambda W: ops.skinny_bmm(hid, W, lb, splits=1, k_of=ranks, row_halves=True)
 elif shape in ("ffn.key.u8", "ffn.value.u8"):
     n, k = (4 * C, C) if shape == "ffn.key.u8" else (C, 4 * C)
     Ws = [ops.tile_weight_u8(torch.randint(0, 256, (n, k), device=dev, dtype=torch.uint8)) for _ in range(NW)]
