@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
+    p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
     p.add_argument("--lora-row-halves", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
     p.add_argument("--skinny-lora-up", type=int, default=None, help="1/0: LoRA up-projections through the hand-written GEMM, A/B only")
@@ -174,7 +175,8 @@ def gemm_shape_timings(model, B):
     g = torch.Generator(device=dev)
     g.manual_seed(6)
     rnd = lambda *shape: torch.randn(shape, generator=g, device=dev).half()
-    gs, rh = model.gemm_splits, model.gemm_row_halves
+    gs = model.gemm_splits
+    rh = model.gemm_row_halves if B >= model.row_halves_min_rows else dict.fromkeys(model.gemm_row_halves, False)
     out = {}
     mixed, rkv = rnd(6, B, C), torch.empty((3, B, C), dtype=torch.float16, device=dev)
     dmax = lws[0].lora1.shape[1]
@@ -214,7 +216,7 @@ def gemm_shape_timings(model, B):
             for lw in lws:
                 ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf, row_halves=rh["ffn_value"])
 
-        out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "unsplit GEMM kernel, two row halves per tile, relu^2 in the epilogue" if (rh["ffn_key"] and B >= 128 and not gs["ffn_key"]) else "GEMM kernel + reduce with relu^2")
+        out["ffn_key"] = (_replay_time(ffn_key, L), 4 * C * C * 2 + B * C * 2 + B * 4 * C * 2, "unsplit GEMM kernel, two row halves per tile, relu^2 in the epilogue" if (rh["ffn_key"] and B >= model.row_halves_min_rows and not gs["ffn_key"]) else "GEMM kernel + reduce with relu^2")
         out["ffn_value"] = (_replay_time(ffn_value, L), 4 * C * C * 2 + B * 4 * C * 2 + B * C * 2, "GEMM kernel (fp32 partials; the reduce is folded into the next LN kernel)")
     elif lws[0].f_K8 is not None:
         pk = torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), B, 4 * C), dtype=torch.float32, device=dev)
@@ -222,7 +224,7 @@ def gemm_shape_timings(model, B):
         xs2, S2 = torch.empty((B, 4 * C), dtype=torch.float16, device=dev), torch.empty((B, ops.mm8_row_parts(4 * C), 3), dtype=torch.float32, device=dev)
 
         kview = [pk]
-        fused_key = model.mm8_fused_key and B >= 128
+        fused_key = model.mm8_fused_key and B >= model.row_halves_min_rows
         S2t = torch.empty((B, ops.mm8_tile_parts(4 * C), 3), dtype=torch.float32, device=dev)
 
         def ffn_key8():
@@ -488,6 +490,8 @@ def main():
         model.gemm_row_halves = dict(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (bool(int(v)) for v in a.row_halves.split(","))))
     if a.split_tmix_min_t is not None:
         model.split_tmix_min_T = a.split_tmix_min_t
+    if a.row_halves_min_rows is not None:
+        model.row_halves_min_rows = a.row_halves_min_rows
     if a.lora_row_halves is not None:
         model.lora_up_row_halves = bool(a.lora_row_halves)
     if a.skinny_key is not None:

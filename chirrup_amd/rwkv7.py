@@ -218,6 +218,7 @@ class RWKV_x070:
         # att.output then needs 4 partial planes instead of 8, ffn.key and the R/K/V + LoRA-down group none (no reduce launches).
         # A/B at 7.2B / bsz 200 on one box (profiles/r02_gemm_experiments.txt section 10): step 7.27 -> 7.09 ms with att.output and
         # ffn.key, another -0.04 ms with R/K/V once the epilogue stored 16 bytes per lane; ffn.value loses with it.
+        self.row_halves_min_rows = 128
         self.gemm_row_halves = {"rkv": True, "att_out": True, "ffn_key": True, "ffn_value": False}
         self.ffn_dtype = ffn_dtype
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
@@ -430,7 +431,7 @@ class RWKV_x070:
         hw = self.skinny_ffn_value and self.skinny_min_rows <= rows <= 256 and C >= self.skinny_min_embd
         use_parts = hw and self.ffn_dtype == torch.float16
         gs = self.gemm_splits
-        rh = self.gemm_row_halves if rows >= 128 else dict.fromkeys(self.gemm_row_halves, False)
+        rh = self.gemm_row_halves if rows >= self.row_halves_min_rows else dict.fromkeys(self.gemm_row_halves, False)
         pbuf = (torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), dtype=torch.float32, device=dev)
                 if use_parts else None)
         pbuf_o = (torch.empty((ops.gemm_splits(C, C, 1, gs["att_out"]), rows, C), dtype=torch.float32, device=dev)
@@ -444,7 +445,7 @@ class RWKV_x070:
             f32 = dict(dtype=torch.float32, device=dev)
             xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
             # ffn.key's corrections + relu^2 + ffn.value's prologue in the key GEMM's epilogue (unsplit launch, row halves)
-            key_fused = self.mm8_fused_key and rows >= 128 and 4 * C < 32768
+            key_fused = self.mm8_fused_key and rows >= self.row_halves_min_rows and 4 * C < 32768
             xs_v = new(rows, 4 * C)
             S_v = torch.empty((rows, ops.mm8_tile_parts(4 * C) if key_fused else ops.mm8_row_parts(4 * C), 3), **f32)
             pbuf_k = None if key_fused else torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), rows, 4 * C), **f32)
