@@ -80,7 +80,7 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                                        const f16 *__restrict__ q_mx = nullptr, const float *__restrict__ q_S = nullptr,
                                        const int q_parts = 0, float *q_sh = nullptr) {
     // q_S: this row's mm8 row sums [q_parts][3] in global memory; they are added up (one wave per sum) into q_sh[3] AFTER the
-    // loads of the row and of its first eight partial planes have been issued, so that their latency is not a stage of its own
+    // loads of the row and of its first four partial planes have been issued, so that their latency is not a stage of its own
     const int nchunk = C >> 3;
     float vals[kLnMaxChunks][8];
     float s = 0.f;
@@ -94,13 +94,13 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
             if (in_row) xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
             if (dpart) {            // delta = binary16(sum of split-K partials): the GEMM's reduce folded into this prologue
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                // up to 8 planes' loads are issued before the first add (one plane per trip costs one memory latency per
-                // plane: 0.8 us each, measured); the adds stay in plane order
-                for (int s0 = 0; s0 < dsplits; s0 += 8) {
+                // four planes' loads are issued before their adds (in plane order); more in flight buys nothing measurable and costs
+                // 32 registers of the 128 a 1024-lane workgroup has per lane
+                for (int s0 = 0; s0 < dsplits; s0 += 4) {
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
-                    f32x4_t p[8][2];
+                    f32x4_t p[4][2];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 4; u++) {
                         if (in_row && s0 + u < dsplits) {
                             p[u][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8));
                             p[u][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8 + 4));
@@ -119,7 +119,7 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                         q_ready = true;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) {
+                    for (int u = 0; u < 4; u++) {
                         if (in_row && s0 + u < dsplits) {
                             acc[0] += p[u][0].x; acc[1] += p[u][0].y; acc[2] += p[u][0].z; acc[3] += p[u][0].w;
                             acc[4] += p[u][1].x; acc[5] += p[u][1].y; acc[6] += p[u][1].z; acc[7] += p[u][1].w;
@@ -177,97 +177,111 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
     }
 }
 
-// One workgroup per (b, t) row.
+// One workgroup per R consecutive (b, t) rows of a sequence.
 template <int NMIX>
 __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
     const int T, const int C, const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
     const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride,
-    const chirrup_mm8_fuse fz) {
+    const chirrup_mm8_fuse fz, const int R) {
     __shared__ float red[3 * (kLnThreads / 64)];
-    const int row = blockIdx.x;
-    const int bb = row / T, t = row - bb * T;
+    // A workgroup takes R consecutive tokens of one sequence: the token shift of row t needs LN(row t-1), which is the row
+    // this workgroup normalised one trip earlier -- only the first of its rows recomputes its predecessor (R = 1, one row per
+    // workgroup, recomputes it for every row with t > 0: twice the loads and arithmetic at T > 1).
+    const int nb = (T + R - 1) / R;
+    const int bb = blockIdx.x / nb, t0 = (blockIdx.x - bb * nb) * R;
     const int64_t slot = slot_idx ? (int64_t)slot_idx[bb] : (int64_t)bb;   // row of the carry tables
     const int nchunk = C >> 3;
-    const int64_t ro = (int64_t)row * C;
-    float cur[kLnMaxChunks][8];
+    float cur[kLnMaxChunks][8], prev[kLnMaxChunks][8];
     const f16 *q_rx = static_cast<const f16 *>(fz.in_rx), *q_mx = static_cast<const f16 *>(fz.in_mx);
     __shared__ float qsum[2][3];                      // mm8 row sums of this row and of its predecessor (ln_row adds the parts up)
-    const float *q_row = fz.in_S ? fz.in_S + (int64_t)row * fz.in_S_parts * 3 : nullptr;
-    ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
-           dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0]);
-    if (NMIX == 0) {
-#pragma unroll
-        for (int q = 0; q < kLnMaxChunks; q++) {
-            const int c = threadIdx.x + q * kLnThreads;
-            if (c < nchunk) {
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = h(cur[q][e]);
-                *reinterpret_cast<f16x8 *>(out + ro + c * 8) = o;
-            }
-        }
-        return;
-    }
-    // token shift: previous row's LN (recomputed) or the carried state for t == 0
-    float prev[kLnMaxChunks][8];
-    if (t == 0) {
-#pragma unroll
-        for (int q = 0; q < kLnMaxChunks; q++) {
-            const int c = threadIdx.x + q * kLnThreads;
-            if (c < nchunk) {
-                const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + slot * C + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; e++) prev[q][e] = (float)pv[e];
-            }
-        }
-    } else {
-        ln_row(x + ro - C, delta ? delta + ro - C : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red,
-               dpart ? dpart + ro - C : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row ? q_row - fz.in_S_parts * 3 : nullptr,
-               fz.in_S_parts, qsum[1]);
-    }
     const f16 *p_ry = static_cast<const f16 *>(fz.out_ry), *p_my = static_cast<const f16 *>(fz.out_my);
     f16 *p_xs = static_cast<f16 *>(fz.out_xs);
-    float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
+    // token shift of the first row: the carried state for t == 0, else the previous row's LN, recomputed
+    if (NMIX > 0) {
+        if (t0 == 0) {
 #pragma unroll
-    for (int q = 0; q < kLnMaxChunks; q++) {
-        const int c = threadIdx.x + q * kLnThreads;
-        if (c < nchunk) {
-            float dx[8];
-            f16x8 cv;
+            for (int q = 0; q < kLnMaxChunks; q++) {
+                const int c = threadIdx.x + q * kLnThreads;
+                if (c < nchunk) {
+                    const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + slot * C + c * 8);
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                dx[e] = (float)h(prev[q][e] - cur[q][e]);
-                cv[e] = h(cur[q][e]);
+                    for (int e = 0; e < 8; e++) prev[q][e] = (float)pv[e];
+                }
             }
-            if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + slot * C + c * 8) = cv;
+        } else {
+            const int64_t rp = ((int64_t)bb * T + t0 - 1) * C;
+            ln_row(x + rp, delta ? delta + rp : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red, dpart ? dpart + rp : nullptr, dsplits,
+                   dsplit_stride, q_rx, q_mx, fz.in_S ? fz.in_S + ((int64_t)bb * T + t0 - 1) * fz.in_S_parts * 3 : nullptr,
+                   fz.in_S_parts, qsum[1]);
+        }
+    }
+    for (int r = 0; r < R; r++) {
+        const int t = t0 + r;
+        if (t >= T) break;
+        const int row = bb * T + t;
+        const int64_t ro = (int64_t)row * C;
+        const float *q_row = fz.in_S ? fz.in_S + (int64_t)row * fz.in_S_parts * 3 : nullptr;
+        ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
+               dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0]);
+        if (NMIX == 0) {
 #pragma unroll
-            for (int m = 0; m < NMIX; m++) {
-                const f16x8 mv = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
-                f16x8 o;
+            for (int q = 0; q < kLnMaxChunks; q++) {
+                const int c = threadIdx.x + q * kLnThreads;
+                if (c < nchunk) {
+                    f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
-                *reinterpret_cast<f16x8 *>(out + (int64_t)m * out_stride + ro + c * 8) = o;
-                if (NMIX == 1 && p_xs) {      // mm8 activation prologue of the GEMM that consumes `out` (mm8_prep_kernel's arithmetic)
-                    const f16x8 rv = *reinterpret_cast<const f16x8 *>(p_ry + c * 8);
-                    const f16x8 yv = *reinterpret_cast<const f16x8 *>(p_my + c * 8);
-                    f16x8 xs;
+                    for (int e = 0; e < 8; e++) o[e] = h(cur[q][e]);
+                    *reinterpret_cast<f16x8 *>(out + ro + c * 8) = o;
+                }
+            }
+            continue;
+        }
+        float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        xs[e] = (f16)((float)o[e] * (float)rv[e]);
-                        ps0 += (float)xs[e];
-                        ps1 += (float)o[e] * (float)yv[e];
-                        ps2 += (float)o[e];
+        for (int q = 0; q < kLnMaxChunks; q++) {
+            const int c = threadIdx.x + q * kLnThreads;
+            if (c < nchunk) {
+                float dx[8];
+                f16x8 cv;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    dx[e] = (float)h(prev[q][e] - cur[q][e]);
+                    cv[e] = h(cur[q][e]);
+                }
+                if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + slot * C + c * 8) = cv;
+#pragma unroll
+                for (int m = 0; m < NMIX; m++) {
+                    const f16x8 mv = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
+                    *reinterpret_cast<f16x8 *>(out + (int64_t)m * out_stride + ro + c * 8) = o;
+                    if (NMIX == 1 && p_xs) {  // mm8 activation prologue of the GEMM that consumes `out` (mm8_prep_kernel's arithmetic)
+                        const f16x8 rv = *reinterpret_cast<const f16x8 *>(p_ry + c * 8);
+                        const f16x8 yv = *reinterpret_cast<const f16x8 *>(p_my + c * 8);
+                        f16x8 xs;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) {
+                            xs[e] = (f16)((float)o[e] * (float)rv[e]);
+                            ps0 += (float)xs[e];
+                            ps1 += (float)o[e] * (float)yv[e];
+                            ps2 += (float)o[e];
+                        }
+                        *reinterpret_cast<f16x8 *>(p_xs + ro + c * 8) = xs;
                     }
-                    *reinterpret_cast<f16x8 *>(p_xs + ro + c * 8) = xs;
                 }
             }
         }
-    }
-    if (NMIX == 1 && p_xs) {
-        block_sum3(ps0, ps1, ps2, red);
-        if (threadIdx.x == 0) fz.out_S[row * 3 + 0] = ps0, fz.out_S[row * 3 + 1] = ps1, fz.out_S[row * 3 + 2] = ps2;
+        if (NMIX == 1 && p_xs) {
+            block_sum3(ps0, ps1, ps2, red);
+            if (threadIdx.x == 0) fz.out_S[row * 3 + 0] = ps0, fz.out_S[row * 3 + 1] = ps1, fz.out_S[row * 3 + 2] = ps2;
+        }
+#pragma unroll
+        for (int q = 0; q < kLnMaxChunks; q++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) prev[q][e] = cur[q][e];
     }
 }
 
@@ -430,10 +444,18 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
         mis16(mix) || mis16(out) || (out_stride & 7))
         return CHIRRUP_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)(B * T)), block(kLnThreads);
+    // rows per workgroup (see the kernel): 1 for short chunks; else enough that the grid is ONE round of the chip's
+    // 512 resident 1024-lane workgroups (a second, mostly empty round costs as much as the first), at most 8
+    int R = 1;
+    if (T >= 8) {
+        R = (int)(((int64_t)B * T + 511) / 512);
+        R = R < 2 ? 2 : (R > 8 ? 8 : R);
+        if (R > T) R = T;
+    }
+    const dim3 grid((unsigned)(B * ((T + R - 1) / R))), block(kLnThreads);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
              (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx, delta_partials, \
-             delta_splits, (int64_t)B * T * C, q
+             delta_splits, (int64_t)B * T * C, q, R
     if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
     else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
     else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);
