@@ -204,6 +204,8 @@ class RWKV_x070:
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
+        self.split_rows_min = 1024                       # library GEMMs from this many rows: ffn.key as two row halves, R/K/V as three launches
+        self.lora_per_problem = True                     # above 256 rows: one library GEMM per LoRA at its own rank, bias in the epilogue
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
@@ -493,7 +495,22 @@ class RWKV_x070:
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
-              if not grouped:
+              if not grouped and not hw and self.lora_per_problem:
+                # more than 256 rows (library GEMMs): one GEMM per LoRA at its own rank (rounded up to a K-block; the rows /
+                # columns beyond the rank are zero) with the bias in the GEMM epilogue.  The batched form multiplies all four
+                # at the widest rank (96/128/128/480 -> 512: 2.4x the flops), runs 4 x [rows, 512, C] at 0.18 PFLOP/s and
+                # expands the bias to [4, rows, C] first: 373 us per layer at 2500 rows against 61 + 56 this way
+                # (profiles/r02_prefill_B25_T100.txt).
+                ups = []
+                hid = None
+                for j in range(p0, 4):
+                    kj = lw.lora_k[j]
+                    hj = F.linear(mixed[2 + j], lw.lora1[j, :kj])                              # [rows, kj]
+                    if j in (1, 3):
+                        ops.lora_act_(hj.unsqueeze(0), j)                                      # tanh(w), sigmoid(g)
+                    ups.append(torch.addmm(lw.lbias[j].view(-1), hj, lw.lora2[j, :, :kj].t()))  # + v0 / w0 / a0 / 0
+                up = ups
+              elif not grouped:
                 hid = torch.bmm(mixed[2 + p0:6], lw.lora1[p0:].transpose(1, 2))
                 ops.lora_act_(hid, p0)                                                        # tanh(w), sigmoid(g)
                 if hw and self.skinny_lora_up and hid.shape[2] % 64 == 0:
@@ -505,11 +522,16 @@ class RWKV_x070:
                 pass
             elif hw and self.skinny_rkv:
                 rkv = ops.skinny_bmm(mixed[0:3], lw.rkv, splits=2)                             # one launch for R, K, V
+            elif rows >= self.split_rows_min:
+                rkv = new(3, rows, C)                       # three GEMMs at 1.15 PFLOP/s instead of one batched launch at 1.0
+                for j in range(3):
+                    torch.mm(mixed[j], lw.rkv[j].t(), out=rkv[j])
             else:
                 rkv = torch.bmm(mixed[0:3], lw.rkv.transpose(1, 2))
             if side is not None:
                 main.wait_stream(side)
-                hid.record_stream(main), up.record_stream(main)
+                for t_ in ([hid] if hid is not None else []) + (list(up) if isinstance(up, list) else [up]):
+                    t_.record_stream(main)
             r, k, v = rkv[0].view(B, T, C), rkv[1].view(B, T, C), rkv[2].view(B, T, C)
             vg_pre = up[0].view(B, T, C) if i > 0 else None
             w, a_pre, g = (up[j - p0].view(B, T, C) for j in (1, 2, 3))
@@ -561,7 +583,16 @@ class RWKV_x070:
                     kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=gs["ffn_key"],
                                            row_halves=rh["ffn_key"])
                 else:
-                    kf = F.linear(kin[0], lw.f_K)
+                    if rows >= self.split_rows_min:
+                        # the library's choice for (rows x C) . (4C x C)^T runs at 0.83 PFLOP/s at 2500 rows, the same product as two
+                        # row halves at 1.16 (tools/exp_prefill_gemm.py: 404 vs 290 us; 1200 rows: 170 vs 151)
+                        kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
+                        kv2, xin = kf.view(rows, 4 * C), kin[0].view(rows, C)
+                        half = (rows + 1) // 2
+                        torch.mm(xin[:half], lw.f_K.t(), out=kv2[:half])
+                        torch.mm(xin[half:], lw.f_K.t(), out=kv2[half:])
+                    else:
+                        kf = F.linear(kin[0], lw.f_K)
                     ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
