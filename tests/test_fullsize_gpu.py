@@ -159,7 +159,8 @@ def test_add_ln_mix_prefill_call_sites_at_production_shape(B, T, n_mix, parts):
 
 
 def test_prefill_chunk_equals_tokens_fed_one_at_a_time_at_production_width(big):
-    """forward_slots with a 25 x 40 chunk (1000 rows: the library-GEMM prefill path, residual stream ping-ponged
+    """forward_slots with a 26 x 40 chunk (1040 rows: the library-GEMM prefill path incl. its forms for >= 1024 rows -- ffn.key in
+    two row halves, one GEMM per LoRA --, row-parallel time-mix around the recurrence-only scan, residual stream ping-ponged
     between two buffers) against the same tokens fed one decode step at a time (200-row regime: ring GEMMs, residual
     updated in place) on a 2-layer C=4096 model: states agree to the rounding noise of 40 tokens.  A delta added twice
     to a row (the race the in-place T > 1 update allowed) would show as an O(1) error."""
@@ -168,7 +169,7 @@ def test_prefill_chunk_equals_tokens_fed_one_at_a_time_at_production_width(big):
     zd, _ = big
     sub = {k: v for k, v in zd.items() if not (k.startswith("blocks.") and int(k.split(".")[1]) >= 2)}
     model = RWKV_x070(_args(), state_dict=sub, device="cuda:0")
-    B, T, n_slots = 25, 40, 32
+    B, T, n_slots = 26, 40, 32
     rng = np.random.default_rng(5)
     toks = rng.integers(1, V, size=(B, T))
     slots = torch.tensor(rng.permutation(n_slots)[:B].astype(np.int32)).cuda()
