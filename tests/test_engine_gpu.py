@@ -71,3 +71,54 @@ def test_engine_from_checkpoint_file_matches_direct_decode(tmp_path):
 
         assert [g[1] for g in got] == [text_of(i) for i in ids]
     assert checked >= 3          # the comparison must not be vacuous
+
+
+def test_engine_process_mode_on_the_gpu_matches_thread_mode(tmp_path):
+    """worker_mode="process" with the REAL worker: a spawned process loads the checkpoint onto the GPU, pulls requests from the
+    shared queue and streams tokens back; greedy ids equal the thread-mode engine's on the same prompts, an abort reaches the
+    worker process, and a prefix state exported by it comes back as host tensors that a later request continues from."""
+    from chirrup_amd.core_structure import ModelLoadConfig
+    from chirrup_amd.engine_core import AsyncEngineCore
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    ckpt = os.path.join(tmp_path, "tiny.pth")
+    torch.save(zd, ckpt)
+    vocab = os.path.join(G, "mini_vocab.txt")
+    prompts = ["hello world", "abc abc abc abc abc abc abc abc", "the quick brown fox", "a b c d e f g"]
+    kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[])
+
+    async def run(mode):
+        eng = AsyncEngineCore(worker_mode=mode)
+        cfg = ModelLoadConfig(model_path=ckpt, vocab_path=vocab, vocab_size=320, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=1, model_config=cfg, batch_size=4), 300)
+        cs = [eng.completion(p, max_tokens=10, **kw) for p in prompts]
+        ids = []
+        for c in cs:
+            ids.append([ev[1] async for ev in c if ev[0] == "token"])
+        extra = {}
+        if mode == "process":
+            assert eng.workers[0].process.is_alive() and eng.workers[0].process.pid != os.getpid()
+            c = eng.completion(prompts[0], max_tokens=10 ** 6, **kw)
+            n = 0
+            async for ev in c:
+                n += 1
+                if n == 4:
+                    c.abort()
+            assert 4 <= n < 2000 and str(c.task.request_status) == "FINISHED_ABORTED"
+            toks = eng.tokenizer.encode(prompts[1])
+            c = eng.completion("", prefill_tokens=list(toks), max_tokens=6, cache_prefill=True, cache_prefill_padding=2, **kw)
+            evs = [ev async for ev in c]
+            cache = [e[1] for e in evs if e[0] == "cache_prefill"]
+            assert len(cache) == 1 and all(t.device.type == "cpu" for t in cache[0]["state"])
+            seen = len(cache[0]["prefilled_tokens"])
+            c2 = eng.completion("", prefill_tokens=toks[seen:], state=cache[0]["state"], max_tokens=6, **kw)
+            extra = {"first": [e[1] for e in evs if e[0] == "token"], "resumed": [ev[1] async for ev in c2 if ev[0] == "token"]}
+        eng.shutdown()
+        return ids, extra
+
+    ids_t, _ = asyncio.run(run("thread"))
+    ids_p, extra = asyncio.run(run("process"))
+    assert all(len(x) == 10 for x in ids_p)
+    assert ids_p == ids_t
+    assert extra["resumed"] == extra["first"] == ids_p[1][:6]
