@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
+    p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
     p.add_argument("--lora-row-halves", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
     p.add_argument("--skinny-key", type=int, default=None, help="1/0: ffn.key through the hand-written GEMM, A/B only")
@@ -490,6 +491,9 @@ def main():
         model.gemm_row_halves = dict(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (bool(int(v)) for v in a.row_halves.split(","))))
     if a.split_tmix_min_t is not None:
         model.split_tmix_min_T = a.split_tmix_min_t
+    if a.no_pair_reduce:
+        from chirrup_amd import ops as _ops
+        _ops.PAIR_REDUCE = False
     if a.row_halves_min_rows is not None:
         model.row_halves_min_rows = a.row_halves_min_rows
     if a.lora_row_halves is not None:

@@ -59,7 +59,9 @@ constexpr int kTileRows = 128;   // rows of one tile image (skinny_tile_weight):
 
 // EPI_MM8 (uint8 weights, unsplit): the rank-1 corrections of the mm8 split form, relu^2 and the activation prologue of the
 // NEXT mm8 product in the GEMM's own epilogue (store_staged_mm8) -- no partials, no reduce launch
-enum { EPI_F16 = 0, EPI_PARTIAL = 1, EPI_MM8 = 2 };
+// EPI_PAIR (binary16 weights, split 2..4, few rows): the last of a tile's workgroups to finish adds the others' partials and its
+// own sums in slice order and applies bias / activation -- no reduce launch (store_staged_sc1 / combine_store)
+enum { EPI_F16 = 0, EPI_PARTIAL = 1, EPI_MM8 = 2, EPI_PAIR = 3 };
 
 // two uint8 -> two binary16 values 1024 + b (exact): bytes b0,b1 -> halves 0x6400|b.  ONE v_perm per pair and no
 // subtraction: the matrix cores multiply by (1024 + q) and the constant is taken out again with the other rank-1 terms of
@@ -81,7 +83,7 @@ __device__ __forceinline__ f16x2 cvt_u8x2(uint32_t packed, int sel_lo) {
 // by its L2 neighbours (ffn.value at bsz 200: x is 6.5 MB, a K-slice 0.8 MB; the L2 is 4 MB).
 // halves = 2 (row halves, BatchStrides::row_halves): the two workgroups of a tile's K-slice are neighbours in that order --
 // on the same XCD when the grid divides by 8 and dispatched together, so the W tile both stream is fetched from HBM once.
-__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch, int &half, const int halves) {
+__device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &batch, int &half, const int halves, const bool pair) {
     const int G = gridDim.x, GS = G * (gridDim.y / halves), total = G * gridDim.y * gridDim.z;
     const int L = blockIdx.x + G * blockIdx.y + G * gridDim.y * blockIdx.z;
     int v = (total & 7) ? L : (L & 7) * (total >> 3) + (L >> 3);
@@ -89,6 +91,14 @@ __device__ __forceinline__ void tile_of_block(int &ngroup, int &kslice, int &bat
     if (halves == 2) {
         half = v & 1;
         v >>= 1;
+    }
+    if (pair) {                                        // the K-slices of a tile as neighbours (same XCD, dispatched together)
+        const int S = gridDim.y;
+        kslice = v % S;
+        v /= S;
+        batch = v / G;
+        ngroup = v - batch * G;
+        return;
     }
     batch = v / GS;
     v -= batch * GS;
@@ -112,6 +122,7 @@ struct BatchStrides {
     int tiled;         // W of every problem is in the tile-image layout (skinny_tile_weight)
     int relu_sq;       // EPI_F16: y = relu(binary16(x.w + bias))^2 in the epilogue
     Mm8Epilogue q8;    // EPI_MM8
+    int *counters;     // EPI_PAIR: one zero-initialised int per tile; the second arriver leaves it zero again
     int row_halves;    // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
@@ -158,6 +169,7 @@ struct Tile {
     int Np, ldy, ngroup, kslice, batch;
     int M;             // rows of x / y this workgroup works on (the launch's M, or its part under row_halves)
     int rows0;         // ... and its first row
+    int pair_id;       // EPI_PAIR: index of the tile's counter
     int act;           // EPI_F16: 0 none, 1 relu^2, 2 tanh, 3 sigmoid (as skinny_reduce_kernel)
     bool w_tiled;
 };
@@ -167,7 +179,8 @@ __device__ __forceinline__ Tile resolve_tile(const int N, const f16 *X, const vo
                                              float *part, const int M, const int ldx, const BatchStrides &bs, const GroupTable &gt) {
     Tile t;
     int half;
-    tile_of_block(t.ngroup, t.kslice, t.batch, half, bs.row_halves ? 2 : 1);
+    tile_of_block(t.ngroup, t.kslice, t.batch, half, bs.row_halves ? 2 : 1, EPI == EPI_PAIR);
+    t.pair_id = t.batch * gridDim.x + t.ngroup;
     t.X = X, t.W = Wv, t.Y = Y, t.bias = bias, t.part = part, t.Np = N, t.ldy = ldy, t.w_tiled = bs.tiled != 0;
     t.M = M, t.act = bs.relu_sq ? 1 : 0;
     const int rows0 = half ? MT * 16 : 0;              // (row_halves launches have M > 16 MT)
@@ -443,6 +456,63 @@ __device__ __forceinline__ void store_staged_mm8(const float *stage, const int M
     }
 }
 
+// EPI_PAIR hand-off of a partial between the two workgroups of a tile (MI355X_MICROARCH.md, inter-workgroup visibility, first
+// row of the table of hand-offs without fences): every byte of the partial is stored write-through (`sc1`), every storing
+// wave drains its stores, the workgroup's barrier, then ONE lane adds to the tile's counter (agent scope); the workgroup whose
+// add came second loads the other partial with `sc1` loads only (they bypass this CU's L1; nothing of it can be in this XCD's
+// L2 -- sc1 stores drop the line).  a + b is the same binary32 value in either order, so the result does not depend on which
+// workgroup was last and equals the reduce launch's bit for bit.  Pays for small slabs only (M <= 32: 16 KB per slice and tile;
+// at M = 200 the lone last arriver needs as long as the whole reduce launch, profiles/r02_gemm_experiments.txt sections 9, 11).
+constexpr int kPairMaxSlices = 4;
+template <int THREADS>
+__device__ __forceinline__ void store_staged_sc1(const float *stage, const int M, const int n_first, const Tile &t, const int kslice) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31;
+    const int n = n_first + 4 * c4;
+    if (n >= t.Np) return;
+    const __amdgpu_buffer_rsrc_t dst = make_rsrc(t.part + (int64_t)kslice * M * t.Np, (int64_t)M * t.Np * 4);
+    for (int m = tid >> 5; m < M; m += THREADS / 32) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + m * kLd + 4 * c4);
+        __builtin_amdgcn_raw_buffer_store_b128(v, dst, (m * t.Np + n) * 4, 0, 16);        // aux 16 = sc1
+    }
+}
+// last arriver: y = epilogue(sum of the K-slices' partials in slice order, its own from the staged sums, the others from memory)
+template <int THREADS>
+__device__ __forceinline__ void combine_store(const float *stage, const int M, const int n_first, const Tile &t, const int own_slice,
+                                              const int slices) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31;
+    const int n = n_first + 4 * c4;
+    if (n >= t.Np) return;
+    constexpr int RP = THREADS / 32;                   // rows per pass
+    const __amdgpu_buffer_rsrc_t src = make_rsrc(t.part, (int64_t)slices * M * t.Np * 4);
+    f16x4 bv = {};
+    if (t.bias) bv = *reinterpret_cast<const f16x4 *>(t.bias + n);
+    for (int m0 = tid >> 5; m0 < M; m0 += RP * 2) {    // two rows x up to three other slices in flight per lane
+        f32x4 oth[2][kPairMaxSlices];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices && k != own_slice)      // (rows past M: within the descriptor, never used)
+                    oth[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((k * M + m0 + u * RP) * t.Np + n) * 4, 0, 16));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int m = m0 + u * RP;
+            if (m >= M) break;
+            const f32x4 own = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 4 * c4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};            // 0 + slice 0 + slice 1 + ...: the reduce kernel's order, also for signed zeros
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices) v += (k == own_slice) ? own : oth[u][k];
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (f16)apply_act(t.bias ? v[e] + (float)bv[e] : v[e], t.act);
+            *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
+        }
+    }
+}
+
 // accumulators of the wave that owns staged columns col0 .. col0+31: acc[nt][mt][i] is m = 16 mt + c, n = col0 + 16 nt + 4q + i
 template <int MT>
 __device__ __forceinline__ void stage_acc(float *stage, const f32x4 (&acc)[2][MT], const int M, const int col0, const int c, const int q) {
@@ -541,8 +611,27 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     __syncthreads();                                   // every compute wave is past its last fragment read
     if (wave_live) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
     __syncthreads();
-    if constexpr (EPI == EPI_MM8) store_staged_mm8<256>(stg, t.M, n_base, t, bs.q8);
-    else store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
+    if constexpr (EPI == EPI_MM8) {
+        store_staged_mm8<256>(stg, t.M, n_base, t, bs.q8);
+    } else if constexpr (EPI == EPI_PAIR) {
+        // the "second" flag goes through the padding columns of the staging rows (a second __shared__ object would
+        // de-pipeline the main loop, cdna_hip_programming.md)
+        store_staged_sc1<256>(stg, t.M, n_base, t, t.kslice);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *const flag = reinterpret_cast<int *>(stg + kTileRows);
+        if (tid == 0) {
+            const int drawn = __hip_atomic_fetch_add(bs.counters + t.pair_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (int)gridDim.y - 1;
+            if (drawn == last) __hip_atomic_store(bs.counters + t.pair_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+            *flag = drawn == last;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the loads below the barrier)
+        if (*flag) combine_store<256>(stg, t.M, n_base, t, t.kslice, (int)gridDim.y);
+    } else {
+        store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -891,7 +980,7 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
     } while (0)
 #define GO(MTV)                                                   \
     do {                                                          \
-        if constexpr (EPI == EPI_MM8) {                           \
+        if constexpr (EPI == EPI_MM8 || EPI == EPI_PAIR) {        \
             if (bn == 256) return CHIRRUP_E_UNSUPPORTED;          \
             GO_K(ring_gemm_kernel, MTV);                          \
         } else {                                                  \
@@ -997,10 +1086,23 @@ inline bool use_halves(int row_halves, int M, int bn) { return row_halves && M >
 inline int tiles_of(int M, bool halves) { return halves ? ((M + 15) / 16 + 1) / 2 : (M + 15) / 16; }
 }  // namespace
 
+// tile_counters (skinny_gemm_f16, skinny_gemm_f16_group; may be NULL): skinny_gemm_pair_counters() ints, ZERO before their
+// first use and used by no other launch that may run concurrently.  With them a launch of at most kPairMaxRows rows whose
+// split count is 2..4 (and (splits - 1) * rows <= 96) needs no reduce launch (EPI_PAIR); the counters are zero again when it ends.
+constexpr int kPairCounters = 4096, kPairMaxRows = 32;   // A/B at 7.2B: bsz 16 -3 %, 48 +-0, 64 +1 % (profiles/r02_gemm_experiments.txt section 11)
+extern "C" int skinny_gemm_pair_counters(void) { return kPairCounters; }
+namespace {
+inline bool use_pair(int s, bool halves, int bn, int M, int tiles, const void *counters) {
+    // (s - 1) slabs of M x 128 binary32 values are read by the last arriver: at most 48 KB
+    return s >= 2 && s <= kPairMaxSlices && (s - 1) * M <= 96 && !halves && bn == 128 && M <= kPairMaxRows && counters &&
+           tiles + 8 <= kPairCounters && !(reinterpret_cast<uintptr_t>(counters) & 3);
+}
+}  // namespace
+
 // Y = act(X . W^T + bias);  W binary16 [N][K] (row stride ldw).  act: 0 none, 1 relu^2.
 extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,
                                const void *bias, void *Y, int ldy, int act, int splits, int row_halves, void *workspace,
-                               void *stream) {
+                               void *tile_counters, void *stream) {
     if (M <= 0 || M > 256 || N <= 0 || K <= 0 || (N & 3) || (K % kKB) || ldx < K || ldw < K || ldy < N || (ldx & 7) || (ldw & 7) || (ldy & 3))
         return CHIRRUP_E_SHAPE;
     if (act < 0 || act > 1) return CHIRRUP_E_UNSUPPORTED;
@@ -1018,6 +1120,12 @@ extern "C" int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, cons
     BatchStrides bs{};
     bs.tiled = w_tiled ? 1 : 0;
     bs.row_halves = halves ? 1 : 0;
+    if (use_pair(s, halves, bn, M, (int)grid.x, tile_counters)) {
+        bs.relu_sq = act == 1 ? 1 : 0;
+        bs.counters = static_cast<int *>(tile_counters);
+        return launch_gemm<false, EPI_PAIR>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy, (const f16 *)bias,
+                                            (float *)workspace, bs);
+    }
     bs.relu_sq = (!partial && act == 1) ? 1 : 0;
     int rc = partial ? launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, N, K, K / s, (const f16 *)X, ldx, W, ldw, (f16 *)Y, ldy,
                                                        (const f16 *)bias, (float *)workspace, bs)
@@ -1126,7 +1234,7 @@ extern "C" int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_ge
 // bias_i); blockIdx.x runs over the exact list of the problems' N-groups.  Unsplit (splits = 1, or the library's choice
 // with row_halves): bias and activation run in the GEMM epilogue; split: through binary32 partials + one reduce launch.
 extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw,
-                                     int splits, int row_halves, void *workspace, void *stream) {
+                                     int splits, int row_halves, void *workspace, void *tile_counters, void *stream) {
     if (count <= 0 || count > 8 || !problems) return CHIRRUP_E_SHAPE;
     if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7) || splits < 0 ||
         (splits > 0 && ((K / kKB) % splits)))
@@ -1165,6 +1273,11 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
     if (s == 1)
         return launch_gemm<false, EPI_F16>(bn, MT, grid, st, M, max_n, K, K, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0], nullptr,
                                            nullptr, bs, gt);
+    if (use_pair(s, halves, bn, M, (int)grid.x, tile_counters)) {
+        bs.counters = static_cast<int *>(tile_counters);
+        return launch_gemm<false, EPI_PAIR>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0], nullptr,
+                                            gt.part[0], bs, gt);
+    }
     int rc = launch_gemm<false, EPI_PARTIAL>(bn, MT, grid, st, M, max_n, K, K / s, gt.X[0], ldx, gt.W[0], ldw, gt.Y[0], gt.ldy[0],
                                              nullptr, gt.part[0], bs, gt);
     if (rc) return rc;

@@ -57,11 +57,12 @@ SIGNATURES = {
     "skinny_gemm_batched_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),
     "skinny_gemm_f16_batched": (_i, [_i, _i, _i, _i, _vp, _i, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i64, _i, _i, _vp, _vp]),
     "skinny_gemm_group_workspace_bytes": (_i64, [_i, _vp, _i, _i, _i]),
-    "skinny_gemm_f16_group": (_i, [_i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp]),
+    "skinny_gemm_f16_group": (_i, [_i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
+    "skinny_gemm_pair_counters": (_i, []),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_tile_weight": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
-    "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "skinny_tile_weight_u8": (_i, [_i, _i, _vp, _i64, _vp, _vp]),

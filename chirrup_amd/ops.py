@@ -102,6 +102,23 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+_pair_counters = {}
+PAIR_REDUCE = True         # False: 2-way splits always go through the reduce launch (A/B; the results are the same bits)
+
+
+def _tile_counters(device):
+    """Zeroed tile counters for the in-launch reduction of 2..4-way splits at <= 32 rows (include/chirrup_amd.h: tile_counters), one
+    set per device and stream like the workspace: launches on one stream run in order, which is all the kernels need."""
+    if not PAIR_REDUCE:
+        return None
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    t = _pair_counters.get(key)
+    if t is None:
+        t = torch.zeros(_lib.load().skinny_gemm_pair_counters(), dtype=torch.int32, device=device)
+        _pair_counters[key] = t
+    return t
+
+
 def spmv_forward(D: int, C: int, vec: torch.Tensor, mat: torch.Tensor, out: torch.Tensor) -> None:
     """rwkv7_state_fwd_fp16::spmv_forward (Albatross/rwkv7.py:66): out += vec @ mat, skipping
     rows where vec is zero. ``out`` must be zeroed by the caller, as in the reference (:65)."""
@@ -416,7 +433,8 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None,
     if bias is not None:
         _chk16("bias", bias, N)
     rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, _ptr(bias),
-                           out.data_ptr(), out.stride(0), act, splits, 1 if row_halves else 0, _ptr(ws), _stream())
+                           out.data_ptr(), out.stride(0), act, splits, 1 if row_halves else 0, _ptr(ws), _ptr(_tile_counters(x.device)),
+                           _stream())
     _lib.check(rc, "skinny_gemm_f16")
     return out
 
@@ -525,7 +543,7 @@ def skinny_group(problems, splits: int = 0, row_halves: bool = False):
     ws = _workspace(nbytes + 256, x0.device)
     base = (ws.data_ptr() + 255) // 256 * 256
     rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), ldw0 if ldw0 is not None else K, splits,
-                                 1 if row_halves else 0, base, _stream())
+                                 1 if row_halves else 0, base, _ptr(_tile_counters(x0.device)), _stream())
     _lib.check(rc, "skinny_gemm_f16_group")
 
 

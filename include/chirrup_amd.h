@@ -254,10 +254,16 @@ typedef struct {
     int w_tiled;       /* w is in the tile-image layout (skinny_tile_weight); needs n % 128 == 0 */
 } chirrup_gemm_problem;
 int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem *problems, int M, int K, int splits);
+/* tile_counters (skinny_gemm_f16_group, skinny_gemm_f16; may be NULL): skinny_gemm_pair_counters() ints, ZERO before their first
+ * use and used by no other launch that may run concurrently (one set per stream).  With them a launch of at most 32 rows whose
+ * split count is 2..4 (at most 48 KB of partials per tile) needs no reduce launch: every K-slice of a
+ * tile writes its binary32 partial, the last to finish adds the partials in slice order (its own from on-chip sums) and applies
+ * bias / activation itself; it leaves the counter at zero.  Bit-identical to the reduce-launch path. */
+int skinny_gemm_pair_counters(void);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
-                          int row_halves, void *workspace, void *stream);
+                          int row_halves, void *workspace, void *tile_counters, void *stream);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
-                    void *Y, int ldy, int act, int splits, int row_halves, void *workspace, void *stream);
+                    void *Y, int ldy, int act, int splits, int row_halves, void *workspace, void *tile_counters, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight

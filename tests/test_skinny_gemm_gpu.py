@@ -374,3 +374,62 @@ def test_mm8_corrections_in_the_gemm_epilogue(B, K, N, halves, tiled):
     y_d = torch.empty(B, N, device=dev, dtype=torch.float16)
     ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=0, y=y_d, tiled=tiled, row_halves=halves)
     assert torch.equal(y_c, y_d)
+
+
+@pytest.mark.parametrize("M,N,K,bias,act", [(32, 8192, 2048, False, 1), (32, 4096, 4096, True, 0), (17, 132, 256, True, 1),
+                                            (1, 128, 128, False, 0), (24, 1000, 512, True, 1), (64, 4096, 1024, True, 1)])
+def test_in_launch_pair_reduction_gives_the_bits_of_the_reduce_launch(M, N, K, bias, act):
+    """At <= 32 rows a 2..4-way K split reduces inside its launch: every K-slice of a tile writes its partial, the last
+    workgroup to finish adds them in slice order (its own from on-chip sums) and applies the epilogue -- the reduce kernel's
+    arithmetic, so the same bits whichever workgroup was last, launch after launch (the counters come back to zero).  (64 rows:
+    the reduce launch either way.)"""
+    from chirrup_amd import ops
+
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") / K ** 0.5).half()
+    b = torch.randn(N, device="cuda").half() if bias else None
+    for splits in (2, 4):                              # 4: in the launch while 3 x M <= 96 rows of partials, else the reduce launch
+        ops.PAIR_REDUCE = False
+        try:
+            want = ops.skinny_linear(x, w, b, act=act, splits=splits)
+        finally:
+            ops.PAIR_REDUCE = True
+        for _ in range(4):
+            got = ops.skinny_linear(x, w, b, act=act, splits=splits)
+            assert torch.equal(got.view(torch.int16), want.view(torch.int16))         # bits, signed zeros included
+        assert int(ops._tile_counters(x.device).abs().sum()) == 0
+        if N % 128 == 0 and K % 64 == 0:
+            assert torch.equal(ops.skinny_linear(x, ops.tile_weight(w), b, act=act, splits=splits), want)
+
+
+def test_in_launch_pair_reduction_of_a_grouped_launch():
+    """The layer's R/K/V + LoRA down-projection launch at 32 rows (seven problems, tanh / sigmoid on two of them) with the
+    in-launch reduction against the same launch followed by the reduce kernel: equal bits, repeatedly."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(11)
+    M, K = 32, 2048
+    mixed = torch.randn(6, M, K, device="cuda").half()
+    rkv = [ops.tile_weight((torch.randn(2048, K, device="cuda") / K ** 0.5).half()) for _ in range(3)]
+    lora1 = (torch.randn(4, 256, K, device="cuda") / K ** 0.5).half()
+    ranks, acts = [64, 64, 64, 256], [None, "tanh", None, "sigmoid"]
+
+    def run():
+        out_rkv = torch.empty(3, M, 2048, device="cuda", dtype=torch.float16)
+        hid = torch.zeros(4, M, 256, device="cuda", dtype=torch.float16)
+        probs = [(mixed[j], rkv[j], out_rkv[j], None, None) for j in range(3)]
+        probs += [(mixed[2 + j], lora1[j, :ranks[j]], hid[j, :, :ranks[j]], None, acts[j]) for j in range(4)]
+        ops.skinny_group(probs, splits=splits)
+        return out_rkv, hid
+
+    for splits in (2, 4):
+        ops.PAIR_REDUCE = False
+        try:
+            want = run()
+        finally:
+            ops.PAIR_REDUCE = True
+        for _ in range(3):
+            got = run()
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert int(ops._tile_counters(mixed.device).abs().sum()) == 0
