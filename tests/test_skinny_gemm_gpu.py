@@ -247,7 +247,8 @@ def test_u8_tile_image_layout_gives_the_same_bits(oracle):
 
 
 @pytest.mark.parametrize("M,N,K,bias,act", [(200, 16384, 4096, False, 1), (200, 4096, 4096, True, 0), (33, 132, 256, True, 1),
-                                            (47, 128, 128, False, 0), (256, 1000, 512, True, 1)])
+                                            (47, 128, 128, False, 0), (256, 1000, 512, True, 1), (40, 128, 64, True, 0),
+                                            (255, 260, 192, False, 1)])
 def test_row_halves_give_the_bits_of_the_whole_rows_launch(M, N, K, bias, act):
     """row_halves: two workgroups per tile and K-slice, one per half of the rows.  A row's sums never depend on the other
     rows, so at the same split count the results -- final values and partial planes -- are bit-identical."""
@@ -334,7 +335,7 @@ def test_row_halves_and_tiled_batch_give_the_same_bits(M):
 
 
 @pytest.mark.parametrize("B,K,N,halves,tiled", [(200, 1024, 4096, True, True), (200, 512, 1024, False, False), (33, 256, 384, True, False),
-                                                 (131, 256, 1000, True, False), (64, 128, 1004, True, False)])
+                                                 (131, 256, 1000, True, False), (64, 128, 1004, True, False), (256, 64, 136, True, False)])
 def test_mm8_corrections_in_the_gemm_epilogue(B, K, N, halves, tiled):
     """mm8t_gemm_fused = mm8t_gemm_partial (unsplit) + mm8_reduce_rows in one launch: the same core sums and the same
     element arithmetic, so y and the next product's xs come out bit-identical; the next product's row sums are split per
