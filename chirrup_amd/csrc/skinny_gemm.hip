@@ -158,7 +158,6 @@ __device__ __forceinline__ void wait_stages_ahead(const int ahead) {
 #undef WAIT_CASE
 }
 
-// W slots of the BN = 128 kernel: what fits in the 160 KiB of LDS beside the two x slots, at most 8 (vmcnt holds 63).
 // What one workgroup works on, resolved from the launch arguments (plain / batched / grouped launch).
 struct Tile {
     const f16 *X;
