@@ -69,6 +69,7 @@ def parse():
     p.add_argument("--skinny-head", type=int, default=None, help="1/0: head GEMM through the hand-written kernel, A/B only")
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
+    p.add_argument("--repeats", type=int, default=10, help="further timed regions of --steps steps after the contract's one (ms_per_step_median)")
     return p.parse_args()
 
 
@@ -257,6 +258,55 @@ def gemm_shape_timings(model, B):
     return out
 
 
+def clock_probes(model, B):
+    """The clock the chip runs at (MHz): without load (one wavefront of dependent VALU work) and inside the main loop of the
+    layer's largest GEMM launches (ffn.key, ffn.value: shader-clock ticks / 100-MHz ticks per workgroup, median over the
+    workgroups of the last of L back-to-back launches; include/chirrup_amd.h: skinny_gemm_clock_probe)."""
+    from chirrup_amd import lib, ops
+
+    L_ = lib.load()
+    dev = model.device
+    out = {}
+    buf = torch.zeros((2,), dtype=torch.int64, device=dev)
+    L_.chirrup_clock_probe(4_000_000, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = buf.tolist()
+    out["idle_mhz"] = round(t[0] / max(t[1], 1) * 100.0, 1)
+    lws = model._layers
+    if B > 256 or lws[0].rkv_t is None or lws[0].f_K_t is None:
+        return out
+    C = model.n_embd
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x_c = torch.randn((B, C), generator=g, device=dev).half()
+    x_4c = torch.randn((B, 4 * C), generator=g, device=dev).half()
+    pbuf = torch.empty((16, B, C), dtype=torch.float32, device=dev)
+    gs = model.gemm_splits
+    rh = model.gemm_row_halves if B >= model.row_halves_min_rows else dict.fromkeys(model.gemm_row_halves, False)
+    pairs = 4096
+    cb = torch.zeros((2 * pairs,), dtype=torch.int64, device=dev)
+
+    def probe(fn):
+        cb.zero_()
+        torch.cuda.synchronize()
+        L_.skinny_gemm_clock_probe(cb.data_ptr(), pairs)
+        try:
+            for lw in lws:
+                fn(lw)
+            torch.cuda.synchronize()
+        finally:
+            L_.skinny_gemm_clock_probe(None, 0)
+        v = cb.view(pairs, 2)
+        v = v[v[:, 1] > 0].double()
+        mhz = (v[:, 0] / v[:, 1] * 100.0).sort().values
+        return {"mhz_median": round(float(mhz[len(mhz) // 2]), 1), "mhz_min": round(float(mhz[0]), 1),
+                "main_loop_us_median": round(float((v[:, 1] / 100.0).sort().values[len(v) // 2]), 2), "workgroups": int(len(v))}
+
+    out["ffn_key_main_loop"] = probe(lambda lw: ops.skinny_linear(x_c, lw.f_K_t, act=1, splits=gs["ffn_key"], row_halves=rh["ffn_key"]))
+    out["ffn_value_main_loop"] = probe(lambda lw: ops.skinny_linear_partial(x_4c, lw.f_V_t, gs["ffn_value"], pbuf, row_halves=rh["ffn_value"]))
+    return out
+
+
 def gemm_roofline_object(timings, L):
     traffic = {}
     for name in ("r02_gemm_pmc_traffic.json", "r02b_gemm_pmc_traffic.json"):       # r02b: the shapes that changed since (row halves)
@@ -340,7 +390,7 @@ def cpu_baseline(name, B, n_layers):
                       f"{t_all:.1f}s measured, scaled to {L} layers"}
 
 
-def timed_decode(model, B, a, dev, rank, steps=None, warmup=None):
+def timed_decode(model, B, a, dev, rank, steps=None, warmup=None, repeats=0):
     """Warm up, then time `steps` decode steps (model step from a HIP graph + the worker's sampling half); returns
     (seconds for the timed steps, max over ranks; the state)."""
     from chirrup_amd import ops
@@ -409,7 +459,10 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None):
 
     for _ in range(warmup):
         timed_step()
-    return timed_region(timed_step, steps, dev), state      # barrier + sync on both sides, max over ranks
+    dt = timed_region(timed_step, steps, dev)               # barrier + sync on both sides, max over ranks: THE contract's region
+    # the same region repeated (boxes and runs differ by more than a round's gains; the median of >= 10 regions is what to compare)
+    a._regions = [timed_region(timed_step, steps, dev) for _ in range(repeats)]
+    return dt, state
 
 
 def engine_iterations(model, B, a, dev, rank, steps):
@@ -514,7 +567,8 @@ def main():
         model.group_tmix_gemms = bool(a.group_tmix)
     if a.skinny_lora_up is not None:
         model.skinny_lora_up = bool(a.skinny_lora_up)
-    dt, state = timed_decode(model, B, a, dev, rank)
+    dt, state = timed_decode(model, B, a, dev, rank, repeats=a.repeats)
+    regions = sorted(r / a.steps * 1e3 for r in a._regions)
 
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
@@ -525,6 +579,7 @@ def main():
         engine_dt = engine_iterations(model, B, a, dev, rank, a.steps)
         state = make_state(model, B)
     gemm_t = gemm_shape_timings(model, B) if rank == 0 else {}
+    clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
     mm8_obj = None
     if rank == 0 and world == 1 and not a.mm8 and not a.no_mm8_leg and not a.no_fused:
         # the int8 channel-mix path north_star names: the same step with uint8 (w8a16) FFN weights (second model, same seed)
@@ -586,8 +641,30 @@ def main():
                                      "host bookkeeping + messages, run-ahead), one worker process per GPU", "ms_per_iteration": round(ems, 4),
                              "value": round(world * B * a.steps / engine_dt, 1), "unit": "tokens/s", "tps_per_request": round(1e3 / ems, 2),
                              "vs_bare_step": round(ems / ms_per_step, 4)}
+        if regions:
+            out["ms_per_step_median"] = round(regions[len(regions) // 2], 4)
+            out["ms_per_step_regions"] = {"n": len(regions), "min": round(regions[0], 4), "max": round(regions[-1], 4),
+                                          "what": f"{len(regions)} further timed regions of {a.steps} steps each, same barrier + sync protocol"}
+        if clocks is not None:
+            out["device_clock"] = clocks
         if gemm_t:
             out["gemm_roofline"] = gemm_roofline_object(gemm_t, L)
+            # the kernel the step spends most of its time in (by time, over a whole step): the 128-column ring GEMM, all its
+            # launches of a layer together, against the same algorithmic bytes
+            ring = {k_: v for k_, v in gemm_t.items() if k_ != "head"}
+            ring_ms = sum(v[0] for v in ring.values()) * L
+            ring_bytes = sum(v[1] for v in ring.values()) * L
+            cand = {"ring_gemm_kernel (all five launches of a layer)": (ring_ms, ring_bytes),
+                    out["roofline"]["kernel"]: (wkv_ms * L, bytes_per_launch * L)}
+            if "head" in gemm_t:
+                cand["wide_gemm_kernel (head)"] = (gemm_t["head"][0], gemm_t["head"][1])
+            top = max(cand, key=lambda k_: cand[k_][0])
+            t_ms, t_b = cand[top]
+            out["roofline_dominant"] = {"bound": "hbm", "kernel": top, "ms_per_step": round(t_ms, 4), "share_of_step": round(t_ms / ms_per_step, 4),
+                                        "algorithmic_bytes_per_step": t_b, "achieved": round(t_b / (t_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": round(t_b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                        "per_launch": {k_: {"launch_us": round(v[0] * 1e3, 2), "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                                       for k_, v in ring.items()}}
         if mm8_obj is not None:
             mm8_obj["vs_fp16_step"] = round(mm8_obj["ms_per_step"] / ms_per_step, 4)
             out["mm8"] = mm8_obj

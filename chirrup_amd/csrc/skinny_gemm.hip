@@ -123,6 +123,7 @@ struct BatchStrides {
     int relu_sq;       // EPI_F16: y = relu(binary16(x.w + bias))^2 in the epilogue
     Mm8Epilogue q8;    // EPI_MM8
     int *counters;     // EPI_PAIR: one zero-initialised int per tile; the second arriver leaves it zero again
+    unsigned long long *clock;   // diagnostic (skinny_gemm_clock_probe): per workgroup {shader-clock ticks, 100-MHz ticks} of the main loop
     int row_halves;    // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
@@ -590,6 +591,8 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         for (int p = 0; p < D - 1; p++)
             if (p < nkb) stage(p);
     }
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (bs.clock) clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     for (int kb = 0; kb < nkb; kb++) {
         if (!computes) {
             const int left = nkb - 1 - kb, ahead = left < D - 2 ? left : D - 2;
@@ -606,6 +609,10 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         }
     }
     if (!computes) return;                             // loader waves are done; finished waves do not count in s_barrier
+    if (bs.clock && tid == 0) {
+        const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        bs.clock[2 * wg] = __builtin_amdgcn_s_memtime() - clk0, bs.clock[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
     float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*16 rows x 528 B <= its size)
     __syncthreads();                                   // every compute wave is past its last fragment read
     if (wave_live) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
@@ -956,6 +963,16 @@ size_t lds_bytes(int bn, int MT, bool w8) {
 
 }  // namespace
 
+// Diagnostic: while set, every 128-column launch writes per workgroup the duration of its main loop in shader-clock ticks and in
+// ticks of the constant 100-MHz counter (their ratio = the clock the CU ran at) to buf[2 * workgroup + {0, 1}]; buf must
+// hold 2 * pairs values for the largest grid launched meanwhile.  Process-wide, not thread-safe: bench.py / tools only.
+static unsigned long long *g_clock_probe = nullptr;
+static int g_clock_pairs = 0;
+extern "C" int skinny_gemm_clock_probe(void *buf, int pairs) {
+    g_clock_probe = static_cast<unsigned long long *>(buf), g_clock_pairs = buf ? pairs : 0;
+    return 0;
+}
+
 template <bool W8, int EPI>
 int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
                 int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
@@ -964,6 +981,7 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
     // tile_of_block deals contiguous runs of tiles to the XCDs only when the workgroup count divides by 8: round the
     // N-group count up (the extra workgroups leave at once)
     while ((grid.x * grid.y * grid.z) & 7) grid.x++;
+    bs.clock = (bn == 128 && g_clock_probe && (int)(grid.x * grid.y * grid.z) <= g_clock_pairs) ? g_clock_probe : nullptr;
 #define GO_K(KERN, MTV)                                                                                                   \
     do {                                                                                                                  \
         auto kern = KERN<MTV, W8, EPI>;                                                                                   \
@@ -1092,8 +1110,12 @@ constexpr int kPairCounters = 4096, kPairMaxRows = 32;   // A/B at 7.2B: bsz 16 
 extern "C" int skinny_gemm_pair_counters(void) { return kPairCounters; }
 namespace {
 inline bool use_pair(int s, bool halves, int bn, int M, int tiles, const void *counters) {
-    // (s - 1) slabs of M x 128 binary32 values are read by the last arriver: at most 48 KB
-    return s >= 2 && s <= kPairMaxSlices && (s - 1) * M <= 96 && !halves && bn == 128 && M <= kPairMaxRows && counters &&
+    // (s - 1) slabs of M x 128 binary32 values are read by the last arriver: at most 48 KB.
+    // The fence-free hand-off is the one-workgroup-per-CU form of MI355X_MICROARCH.md: hold that by construction -- a workgroup
+    // of this launch must take more than half of the CU's 160 KiB of LDS (today 108-120 KiB at 1-2 x tiles; a shallower ring
+    // would silently allow two per CU).
+    const bool one_per_cu = lds_bytes(bn, (M + 15) / 16, false) > 80 * 1024;
+    return s >= 2 && s <= kPairMaxSlices && (s - 1) * M <= 96 && !halves && bn == 128 && M <= kPairMaxRows && counters && one_per_cu &&
            tiles + 8 <= kPairCounters && !(reinterpret_cast<uintptr_t>(counters) & 3);
 }
 }  // namespace

@@ -66,6 +66,7 @@ class AsyncEngineCore:
         self.worker_mode = worker_mode
         self._worker_kwargs = dict(worker_kwargs or {})
         self._router = None
+        self._monitor = None
         self._result_q = None
         self.workers: List[Any] = []
         self.worker_threads: List[threading.Thread] = []
@@ -101,10 +102,13 @@ class AsyncEngineCore:
         self.workers = ep.spawn_workers(worker_num, model_config, batch_size, self._worker_factory, self._worker_kwargs,
                                         self._result_q, mp_task_q)
         self._router.start()
+        self._monitor = ep.LivenessMonitor(self.workers, self._result_q, lambda: self.is_shutdown)
+        self._monitor.start()
 
     def _on_process_worker_exit(self, worker_id: str, kind: str) -> None:
-        """Router thread: a worker process reported an error or ended.  Its requests are completed as aborted (its own
-        loop does that when it can; this covers a hard exit), and so are the queued ones when no worker is left."""
+        """Router thread: a worker process reported an error or ended -- by its own message, or, for a hard exit (HIP abort,
+        segmentation fault, kill), by the LivenessMonitor that watches the process sentinels.  Its requests are completed as
+        aborted (its own loop does that when it can), and so are the queued ones when no worker is left."""
         if self.is_shutdown or self._router is None:
             return
         for task in self._router.tasks_of(worker_id):
@@ -223,6 +227,8 @@ class AsyncEngineCore:
             return
         self.is_shutdown = True
         if self.worker_mode == "process" and self._router is not None:
+            if self._monitor is not None:
+                self._monitor.stop()
             for w in self.workers:
                 w.control_q.put({"type": "shutdown"})
                 w.abort_q.put(None)

@@ -17,8 +17,10 @@ Prefix states cross the process boundary as host tensors (torch's shared-memory 
 with ``state_cache_device="cpu"``; an HBM-resident arena needs the workers in the engine's own process (thread mode).
 """
 import multiprocessing as mp
+import multiprocessing.connection
 import queue
 import threading
+from collections import OrderedDict
 from typing import Any, Callable, Dict, List, Optional
 
 from .core_structure import ModelLoadConfig, RequestStatus, Task
@@ -85,9 +87,12 @@ class RemoteTaskQueue:
     """task_queue of a worker process: a task leaves the shared queue only when this worker has a free slot for it, so
     the pull-based balancing of the reference (worker.py:583) carries over unchanged."""
 
+    EARLY_ABORTS = 4096                                 # ids remembered for tasks nobody has pulled yet (oldest dropped first)
+
     def __init__(self, task_q, result_q, worker_id: str):
         self._q, self._result_q, self._wid = task_q, result_q, worker_id
         self.local_events: Dict[str, queue.Queue] = {}
+        self._early_aborts: "OrderedDict[str, None]" = OrderedDict()
         self._lock = threading.Lock()
 
     def get_nowait(self) -> Task:
@@ -95,12 +100,22 @@ class RemoteTaskQueue:
         ev = queue.Queue()
         with self._lock:
             self.local_events[d["task_id"]] = ev
+            # an abort that was broadcast while the task still sat in the shared queue (or between the pull above and this
+            # insert): the task's own event queue carries it, as in thread mode and in the reference (interface.py:140-142),
+            # and the worker sees it on admission (worker.py:443)
+            if self._early_aborts.pop(d["task_id"], 0) is None:
+                ev.put_nowait(("abort", None))
         self._result_q.put((d["task_id"], ("__accepted__", self._wid)))
         return Task(output_queue=ResultSink(self._result_q, d["task_id"], on_done=self.forget), task_event_queue=ev, **d)
 
     def deliver_abort(self, task_id: str) -> None:
         with self._lock:
             ev = self.local_events.get(task_id)
+            if ev is None:                              # not pulled by THIS worker (yet): remember it, bounded
+                self._early_aborts[task_id] = None
+                self._early_aborts.move_to_end(task_id)
+                while len(self._early_aborts) > self.EARLY_ABORTS:
+                    self._early_aborts.popitem(last=False)
         if ev is not None:
             ev.put_nowait(("abort", None))
 
@@ -113,16 +128,6 @@ def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLo
                         control_q, abort_q, worker_factory: Optional[Callable[..., Any]], worker_kwargs: Dict[str, Any]) -> None:
     """Entry point of a worker process (spawned: nothing of the parent's CUDA/HIP state is inherited)."""
     tasks = RemoteTaskQueue(task_q, result_q, worker_id)
-    kw = dict(worker_id=worker_id, gpu_id=gpu_id, model_config=model_config, task_queue=tasks,
-              master_event_queue=ControlQueue(control_q), worker_event_queue=WorkerEventSink(result_q), batch_size=batch_size)
-    kw.update(worker_kwargs)
-    if worker_factory is not None:
-        w = worker_factory(**kw)
-    else:
-        from .worker import Worker
-
-        kw.setdefault("state_cache_device", "cpu")
-        w = Worker(**kw)
 
     def listen():
         while True:
@@ -132,8 +137,21 @@ def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLo
             tasks.deliver_abort(tid)
 
     threading.Thread(target=listen, daemon=True, name=f"chirrup:{worker_id}:aborts").start()
-    try:
+    try:                                                # construction included: an exception there must reach the engine too
+        kw = dict(worker_id=worker_id, gpu_id=gpu_id, model_config=model_config, task_queue=tasks,
+                  master_event_queue=ControlQueue(control_q), worker_event_queue=WorkerEventSink(result_q), batch_size=batch_size)
+        kw.update(worker_kwargs)
+        if worker_factory is not None:
+            w = worker_factory(**kw)
+        else:
+            from .worker import Worker
+
+            kw.setdefault("state_cache_device", "cpu")
+            w = Worker(**kw)
         w.start()
+    except BaseException as e:                          # noqa: BLE001 -- reported, then re-raised
+        result_q.put(("__worker_event__", (worker_id, "worker_error", {"error": f"{type(e).__name__}: {e}"})))
+        raise
     finally:
         result_q.put(("__worker_event__", (worker_id, "worker_exit", {})))
 
@@ -239,6 +257,41 @@ class ProcessWorkerHandle:
 
     def is_alive(self) -> bool:
         return self.process.is_alive()
+
+
+class LivenessMonitor(threading.Thread):
+    """Engine-side watch over the worker PROCESSES.  A worker that ends without its own goodbye -- a HIP abort or a
+    segmentation fault on a GPU fault, an out-of-memory kill, os._exit -- never sends "worker_exit" (that message comes from a
+    `finally` of the worker's Python code); its clients would wait forever and init() would sit out its 300-s load timeout.
+    This thread waits on the processes' sentinels and, for a process that ended while the engine is not shutting down, posts a
+    "worker_error" event (init() fails fast on it) and "worker_exit" (the router completes the worker's requests as aborted).
+    Nothing is restarted."""
+
+    def __init__(self, handles, result_q, is_shutdown: Callable[[], bool]):
+        super().__init__(daemon=True, name="chirrup:liveness")
+        self._handles, self._q, self._is_shutdown = list(handles), result_q, is_shutdown
+        self._stop_r, self._stop_w = mp.Pipe(duplex=False)
+
+    def stop(self):
+        try:
+            self._stop_w.send(None)
+        except (OSError, ValueError):
+            pass
+
+    def run(self):
+        live = {h.process.sentinel: h for h in self._handles}
+        while live:
+            ready = multiprocessing.connection.wait(list(live) + [self._stop_r])
+            if self._stop_r in ready:
+                return
+            for s_ in ready:
+                h = live.pop(s_)
+                if self._is_shutdown():
+                    continue
+                code = h.process.exitcode
+                self._q.put(("__worker_event__", (h.worker_id, "worker_error",
+                                                  {"error": f"worker process ended unexpectedly (exit code {code})"})))
+                self._q.put(("__worker_event__", (h.worker_id, "worker_exit", {})))
 
 
 def spawn_workers(worker_num: int, model_config: ModelLoadConfig, batch_size: int, worker_factory, worker_kwargs, result_q, task_q):

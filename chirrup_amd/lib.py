@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("CHIRRUP_AMD_LIB") or os.path.join(_HERE, "libchirrup_
 _lib = None
 _lock = threading.Lock()      # worker threads may race to the first load
 
+ABI_VERSION = 2               # CHIRRUP_ABI_VERSION of include/chirrup_amd.h this module's SIGNATURES were written against
+
 E_NAMES = {-1: "CHIRRUP_E_SHAPE", -2: "CHIRRUP_E_NULL", -3: "CHIRRUP_E_ALIGN", -4: "CHIRRUP_E_UNSUPPORTED"}
 
 # name -> (restype, argtypes); mirrors include/chirrup_amd.h one to one
@@ -59,6 +61,8 @@ SIGNATURES = {
     "skinny_gemm_group_workspace_bytes": (_i64, [_i, _vp, _i, _i, _i]),
     "skinny_gemm_f16_group": (_i, [_i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "skinny_gemm_pair_counters": (_i, []),
+    "skinny_gemm_clock_probe": (_i, [_vp, _i]),
+    "chirrup_clock_probe": (_i, [_i, _vp, _vp]),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_tile_weight": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
@@ -97,6 +101,11 @@ def load():
             L = ctypes.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover
             raise ChirrupAmdError(f"cannot load {LIB_PATH}: {e}") from e
+        L.chirrup_abi_version.restype = ctypes.c_int
+        have = L.chirrup_abi_version()
+        if have != ABI_VERSION:       # a stale build: its entry points would read `stream` where the workspace now stands
+            raise ChirrupAmdError(f"{LIB_PATH} has ABI version {have}, this package needs {ABI_VERSION}: rebuild it "
+                                  "(make -C chirrup_amd/csrc)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -2,7 +2,7 @@
 
 Same names, argument order and in-place behaviour as the reference's
 ``torch.ops.rwkv7_state_fwd_fp16.{forward_one,forward_seq,spmv_forward}``
-(Albatross/cuda/rwkv7_state_fwd_fp16.cpp:10-25) and ``torch.ops.rwkv_pip.{mm8_seq,mm8_one}``
+(Albatross/cuda/rwkv7_state_fwd_fp16.cpp:10-25) and ``torch.ops.rwkv_pip.{mm8_seq,mm8_seq_opt,mm8_one,gemm_fp16_cublas}``
 (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-119, :206-211), implemented by the HIP kernels behind
 the C ABI (include/chirrup_amd.h).  torch tensors are only carriers of device pointers here.
 
@@ -119,6 +119,24 @@ def _tile_counters(device):
     return t
 
 
+def reset_tile_counters(device=None) -> None:
+    """Zero the tile counters of the current stream (a memset node when the stream is capturing): a launch that did not complete
+    may have left them non-zero (include/chirrup_amd.h: tile_counters)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    t = _tile_counters(dev)
+    if t is not None:
+        t.zero_()
+
+
+def _check_gemm(rc: int, what: str, device) -> None:
+    if rc != 0 and PAIR_REDUCE:
+        try:
+            reset_tile_counters(device)
+        except Exception:          # noqa: BLE001 -- the original error is the one to report
+            pass
+    _lib.check(rc, what)
+
+
 def spmv_forward(D: int, C: int, vec: torch.Tensor, mat: torch.Tensor, out: torch.Tensor) -> None:
     """rwkv7_state_fwd_fp16::spmv_forward (Albatross/rwkv7.py:66): out += vec @ mat, skipping
     rows where vec is zero. ``out`` must be zeroed by the caller, as in the reference (:65)."""
@@ -158,7 +176,7 @@ def _mm8_check(B, N, M, x, w, mx, rx, my, ry, y):
 # (mm8_pack) runs once per tensor.  Keyed by (address, in-place version counter, shape); an entry keeps its source
 # tensor alive, so the address cannot be handed to another tensor while the entry exists.  Bounded by bytes.
 _MM8_PACK_CACHE: "OrderedDict" = None
-MM8_PACK_CACHE_BYTES = 32 << 30
+MM8_PACK_CACHE_BYTES = None      # None: a quarter of the HBM that is free at the first packed call, at most 32 GiB; set explicitly to override
 
 
 def _mm8_packed(w: torch.Tensor, N: int, M: int) -> Optional[torch.Tensor]:
@@ -167,9 +185,12 @@ def _mm8_packed(w: torch.Tensor, N: int, M: int) -> Optional[torch.Tensor]:
     L = _lib.load()
     if L.mm8_packed_bytes(N, M) == 0 or (w.stride(0) & 15) or (w.data_ptr() & 15):
         return None
+    global MM8_PACK_CACHE_BYTES
     if _MM8_PACK_CACHE is None:
         from collections import OrderedDict
         _MM8_PACK_CACHE = OrderedDict()
+    if MM8_PACK_CACHE_BYTES is None:
+        MM8_PACK_CACHE_BYTES = min(32 << 30, torch.cuda.mem_get_info(w.device)[0] // 4)
     key = (w.device.index, w.data_ptr(), w._version, N, M, w.stride(0))
     hit = _MM8_PACK_CACHE.get(key)
     if hit is not None:
@@ -190,10 +211,21 @@ def _mm8_packed(w: torch.Tensor, N: int, M: int) -> Optional[torch.Tensor]:
 def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
     """rwkv_pip::mm8_seq / mm8_seq_opt (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84, :206-211):
     y[B,M] = x[B,N] @ dequant(w[N,M]), on the matrix cores (include/chirrup_amd.h: mm8_seq).  The weight is packed
-    once per tensor (see _mm8_packed); shapes the packed layout cannot hold run the as-coded kernel."""
+    once per tensor (see _mm8_packed); shapes the packed layout cannot hold, and operands that miss mm8t_seq's alignment
+    (views of the scale vectors, odd strides), run the as-coded kernel.
+
+    Arithmetic: the SPLIT form -- xs = binary16(x*ry), core = xs . (1024 + q) in binary32 on the matrix cores, then
+    y = rx*(core - 1023.5*sum xs) + sum x*my + mx*sum x.  That is the form of the reference's own half-precision
+    `mm8_seq_opt` (rwkv_pip_wrapper.cpp:148-191: preprocess / cuBLAS / postprocess, which additionally keeps `core` in
+    binary16); the reference's `mm8_seq` evaluates the as-coded expression with binary32 accumulation (rwkv_pip_operators.cu:
+    59-83), so under THAT name this op differs from the reference by the rounding of xs (<= 2e-3 of the row scale, bounded
+    against oracle_mm8_seq in tests/test_mm8_spmv_gpu.py); `mm8_seq_direct` is the bit-exact as-coded kernel."""
     L = _lib.load()
     mx, rx, my, ry = _mm8_check(B, N, M, x, w, mx, rx, my, ry, y)
-    packed = _mm8_packed(w, N, M) if (x.stride(0) % 8 == 0 and y.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0) else None
+    # mm8t_seq's preconditions (include/chirrup_amd.h): anything else runs the as-coded kernel instead of failing with E_ALIGN
+    aligned = (x.stride(0) % 8 == 0 and y.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and y.data_ptr() % 8 == 0 and
+               mx.data_ptr() % 8 == 0 and rx.data_ptr() % 8 == 0 and my.data_ptr() % 16 == 0 and ry.data_ptr() % 16 == 0)
+    packed = _mm8_packed(w, N, M) if aligned else None
     if packed is None:
         rc = L.mm8_seq_direct(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(),
                               my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), _stream())
@@ -435,7 +467,7 @@ def skinny_linear(x, weight, bias=None, act: int = 0, splits: int = 0, out=None,
     rc = L.skinny_gemm_f16(M, N, K, x.data_ptr(), x.stride(0), wptr, ldw, w_tiled, _ptr(bias),
                            out.data_ptr(), out.stride(0), act, splits, 1 if row_halves else 0, _ptr(ws), _ptr(_tile_counters(x.device)),
                            _stream())
-    _lib.check(rc, "skinny_gemm_f16")
+    _check_gemm(rc, "skinny_gemm_f16", x.device)
     return out
 
 
@@ -544,7 +576,7 @@ def skinny_group(problems, splits: int = 0, row_halves: bool = False):
     base = (ws.data_ptr() + 255) // 256 * 256
     rc = L.skinny_gemm_f16_group(len(problems), ctypes.addressof(arr), M, K, x0.stride(0), ldw0 if ldw0 is not None else K, splits,
                                  1 if row_halves else 0, base, _ptr(_tile_counters(x0.device)), _stream())
-    _lib.check(rc, "skinny_gemm_f16_group")
+    _check_gemm(rc, "skinny_gemm_f16_group", x0.device)
 
 
 def skinny_linear_partial(x, weight, splits: int, partials, row_halves: bool = False):
@@ -707,6 +739,29 @@ def lora_act_(hbuf, first_plane: int) -> None:
     _lib.check(rc, "rwkv7_lora_act")
 
 
+def gemm_fp16_cublas(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> None:
+    """rwkv_pip::gemm_fp16_cublas (scripts/test_mm8/gemm_fp16_cublas.cpp:29-74, registered at rwkv_pip_wrapper.cpp:210):
+    c = a @ b for row-major binary16 a [.., m, k] and b [.., k, n] (2-D, or 3-D batched with equal leading size), binary32
+    compute, c binary16 or binary32, written in place.  The reference hands the product to cuBLAS; here it goes to the ROCm
+    BLAS torch links (hipBLASLt) -- a library pass-through, this op exists so that scripts written against torch.ops.rwkv_pip
+    bind unchanged.  Like the reference it assumes dense row-major operands (it passes ld = the inner size)."""
+    for name, t in (("a", a), ("b", b)):
+        if not t.is_cuda or t.dtype != torch.float16 or not t.is_contiguous():
+            raise _lib.ChirrupAmdError(f"{name}: expected a contiguous GPU fp16 tensor")
+    if not c.is_cuda or c.dtype not in (torch.float16, torch.float32) or not c.is_contiguous():
+        raise _lib.ChirrupAmdError("c: expected a contiguous GPU fp16 or fp32 tensor")
+    if a.dim() != b.dim() or a.dim() not in (2, 3) or a.shape[-1] != b.shape[-2] or (a.dim() == 3 and a.shape[0] != b.shape[0]):
+        raise _lib.ChirrupAmdError("gemm_fp16_cublas: expected a [.., m, k], b [.., k, n] (both 2-D or both 3-D)")
+    if tuple(c.shape) != tuple(a.shape[:-1]) + (b.shape[-1],):
+        raise _lib.ChirrupAmdError("c: expected shape a.shape[:-1] + (n,)")
+    if c.dtype == torch.float16:
+        torch.matmul(a, b, out=c)
+    elif a.dim() == 2:
+        torch.mm(a, b, out_dtype=torch.float32, out=c)      # binary16 operands, binary32 accumulate AND output (CUDA_R_32F c)
+    else:
+        torch.bmm(a, b, out_dtype=torch.float32, out=c)
+
+
 _registered = False
 
 
@@ -732,6 +787,7 @@ def register_torch_ops() -> None:
             "mm8_seq": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
             "mm8_seq_opt": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
             "mm8_one": (f"(int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_one),
+            "gemm_fp16_cublas": (f"({T} a, {T} b, {T}(a!) c) -> ()", gemm_fp16_cublas),
         },
     }
     keep = []

@@ -682,6 +682,7 @@ class DecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            ops.reset_tile_counters(model.device)         # a memset node: every replay starts from zeroed tile counters
             self.logits = model.forward_seq_batch(self.tokens, state)
         torch.cuda.synchronize()
         for t, s in zip(state, snap):
@@ -727,6 +728,7 @@ class SlotDecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            ops.reset_tile_counters(dev)                  # a memset node: every replay starts from zeroed tile counters
             self.logits = fwd()
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):

@@ -27,7 +27,13 @@ extern "C" {
 #define CHIRRUP_E_ALIGN (-3)     /* pointer / stride not aligned as documented */
 #define CHIRRUP_E_UNSUPPORTED (-4)
 
-/* Library / ABI version and the gfx target the kernels were built for ("gfx950"). */
+/* Library / ABI version and the gfx target the kernels were built for ("gfx950").
+ * CHIRRUP_ABI_VERSION changes whenever an exported prototype changes incompatibly; a caller compares it with
+ * chirrup_abi_version() of the library it loaded before making any other call (chirrup_amd/lib.py does).
+ *   1  round 1
+ *   2  round 2: skinny_gemm_f16 / _f16_group / _f16_partial gained row_halves (and tile_counters) ahead of `stream`,
+ *      skinny_gemm_f16_grouped gained w_tiled, skinny_gemm_group_workspace_bytes gained K, skinny_gemm_select removed */
+#define CHIRRUP_ABI_VERSION 2
 int chirrup_abi_version(void);
 const char *chirrup_target_arch(void);
 
@@ -258,8 +264,22 @@ int64_t skinny_gemm_group_workspace_bytes(int count, const chirrup_gemm_problem 
  * use and used by no other launch that may run concurrently (one set per stream).  With them a launch of at most 32 rows whose
  * split count is 2..4 (at most 48 KB of partials per tile) needs no reduce launch: every K-slice of a
  * tile writes its binary32 partial, the last to finish adds the partials in slice order (its own from on-chip sums) and applies
- * bias / activation itself; it leaves the counter at zero.  Bit-identical to the reduce-launch path. */
+ * bias / activation itself; it leaves the counter at zero.  Bit-identical to the reduce-launch path.
+ * The hand-off between the workgroups uses write-through stores, one agent-scope atomic per workgroup and L1-bypassing loads, no
+ * fences -- a form measured on gfx950 for ONE workgroup per CU and memory from hipMalloc (MI355X_MICROARCH.md, inter-workgroup
+ * visibility): `workspace` and `tile_counters` must be hipMalloc'ed device memory (not host-mapped, not managed), and the library
+ * only takes this path for launches whose workgroups need more than half of a CU's LDS (so that two can never share a CU).
+ * A launch that does not complete (device fault, process killed) may leave counters non-zero: zero them again before reuse --
+ * chirrup_amd does so at the head of every captured decode graph and after any failed call. */
 int skinny_gemm_pair_counters(void);
+/* Diagnostic for bench.py / tools (process-wide, not thread-safe): while buf != NULL every 128-column GEMM launch of at most
+ * `pairs` workgroups writes, per workgroup, the duration of its main loop as {shader-clock ticks (s_memtime), ticks of the
+ * constant 100-MHz counter (s_memrealtime)} into buf (uint64 [2 * pairs]); ticks / (100-MHz ticks) * 100 = the clock in MHz the
+ * CU ran the loop at.  buf = NULL switches it off again. */
+int skinny_gemm_clock_probe(void *buf, int pairs);
+/* The chip's clock without load: one wavefront spins `iters` dependent VALU operations; out (uint64 [2]) receives {shader-clock
+ * ticks, 100-MHz ticks}. */
+int chirrup_clock_probe(int iters, void *out, void *stream);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
                           int row_halves, void *workspace, void *tile_counters, void *stream);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,

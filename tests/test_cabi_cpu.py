@@ -32,7 +32,8 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(L, name), f"{name} declared in include/chirrup_amd.h but not exported"
         assert name in lib.SIGNATURES, f"{name} has no ctypes signature in chirrup_amd/lib.py"
-    assert L.chirrup_abi_version() >= 1
+    header = open(os.path.join(ROOT, "include", "chirrup_amd.h")).read()
+    assert int(re.search(r"#define\s+CHIRRUP_ABI_VERSION\s+(\d+)", header).group(1)) == lib.ABI_VERSION == L.chirrup_abi_version() == 2
     assert L.chirrup_target_arch() == b"gfx950"
 
 
@@ -72,5 +73,5 @@ def test_torch_op_registration_uses_reference_names():
     ops.register_torch_ops()
     for name in ("forward_one", "forward_seq", "spmv_forward"):
         assert hasattr(torch.ops.rwkv7_state_fwd_fp16, name)
-    for name in ("mm8_seq", "mm8_one", "mm8_seq_opt"):
+    for name in ("mm8_seq", "mm8_one", "mm8_seq_opt", "gemm_fp16_cublas"):      # rwkv_pip_wrapper.cpp:206-211: all four
         assert hasattr(torch.ops.rwkv_pip, name)

@@ -144,3 +144,92 @@ def test_engine_with_one_process_per_worker():
 
     asyncio.run(main())
     assert not torch.cuda.is_initialized()
+
+
+def test_abort_of_a_request_that_no_worker_has_pulled_yet():
+    """Process mode, round-2 advisor finding: the abort of a request that still sits in the shared queue (every slot busy) is
+    broadcast by task id before any worker owns the task.  The workers remember such ids (bounded), and the one that pulls the
+    task later finds the abort in the task's own event queue on admission -- FINISHED_ABORTED, as in thread mode and the
+    reference (interface.py:140-142, worker.py:443), instead of running to max_tokens."""
+    async def main():
+        eng = AsyncEngineCore(worker_factory=_process_factory, tokenizer=_Tok(), worker_mode="process")
+        cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=1, model_config=cfg, batch_size=3), 120)      # 2 request slots + the scratch slot
+        kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[])
+        busy = [eng.completion("", prefill_tokens=[1, 2, 3 + i], max_tokens=10 ** 6, **kw) for i in range(2)]    # fill both slots
+        its = [b.__aiter__() for b in busy]
+        for it in its:
+            await asyncio.wait_for(it.__anext__(), 30)                      # both are running
+        queued = eng.completion("", prefill_tokens=[7, 7], max_tokens=10 ** 6, **kw)
+        qit = queued.__aiter__()                                             # puts the task on the shared queue
+        first = asyncio.ensure_future(qit.__anext__())
+        await asyncio.sleep(0.3)
+        assert queued.task.task_id not in eng._router.owner                  # nobody has pulled it: no free slot
+        queued.abort()
+        await asyncio.sleep(0.3)
+        for b in busy:                                                       # now free the slots
+            b.abort()
+        for it in its:
+            async for _ in it:
+                pass
+        n = 0
+        try:
+            await asyncio.wait_for(first, 30)
+            n += 1
+            async for _ in qit:
+                n += 1
+        except StopAsyncIteration:
+            pass
+        assert str(queued.task.request_status) == "FINISHED_ABORTED" and n < 50, (queued.task.request_status, n)
+        eng.shutdown()
+
+    asyncio.run(main())
+
+
+class _DyingModel(FakeModel):
+    """Ends its process the hard way in the middle of a request (what a HIP abort on a GPU fault looks like from outside)."""
+    calls = 0
+
+    def forward_slots(self, *a, **k):
+        type(self).calls += 1
+        if type(self).calls >= 4:
+            import os
+
+            os._exit(1)
+        return super().forward_slots(*a, **k)
+
+
+def _dying_factory(**kw):
+    return Worker(model=_DyingModel(), tokenizer=_Tok(), penalize_argmax=cpu_penalize_argmax, **kw)
+
+
+def _ctor_raises_factory(**kw):
+    raise RuntimeError("cannot build the worker")
+
+
+def test_hard_exit_of_a_worker_process_releases_its_clients_and_fails_init_fast():
+    """Process mode, round-2 advisor finding: a worker process that dies without a goodbye (os._exit here; a HIP abort, a
+    segmentation fault or an OOM kill in production) is noticed by the engine's liveness monitor on the process sentinel:
+    running and queued requests complete as aborted (nothing is restarted); and a worker whose CONSTRUCTOR raises fails
+    init() at once instead of after the 300-s load timeout."""
+    import time
+
+    async def main():
+        eng = AsyncEngineCore(worker_factory=_dying_factory, tokenizer=_Tok(), worker_mode="process")
+        cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=1, model_config=cfg, batch_size=3), 120)
+        kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=10 ** 6)
+        cs = [eng.completion("", prefill_tokens=[1, 2, 3], **kw) for _ in range(4)]         # two running, two queued
+        await asyncio.wait_for(asyncio.gather(*[c.get_full_completion() for c in cs]), 60)
+        assert all(str(c.task.request_status) == "FINISHED_ABORTED" for c in cs)
+        assert not eng.workers[0].is_alive() and eng.workers[0].process.exitcode == 1
+        eng.shutdown()
+
+        eng = AsyncEngineCore(worker_factory=_ctor_raises_factory, tokenizer=_Tok(), worker_mode="process")
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="failed to load"):
+            await asyncio.wait_for(eng.init(worker_num=1, model_config=cfg, batch_size=2), 120)
+        assert time.time() - t0 < 60
+        eng.shutdown()
+
+    asyncio.run(main())

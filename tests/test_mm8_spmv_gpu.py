@@ -162,3 +162,60 @@ def test_spmv_vs_oracle(oracle, D, C, density):
     # Triton-surface wrapper returns a fresh tensor
     z = ops.rwkv_mm_sparsity(torch.from_numpy(vec).cuda(), torch.from_numpy(mat).cuda())
     assert np.array_equal(bits(z.cpu().numpy()), bits(got))
+
+
+def test_mm8_seq_op_with_operands_the_packed_path_cannot_take(oracle):
+    """Round-2 advisor finding: scale vectors that are VIEWS off a 16-byte boundary (my / ry) or off an 8-byte boundary
+    (mx / rx), or an output whose rows are 4-byte aligned only, used to reach mm8t_seq and come back as CHIRRUP_E_ALIGN; the
+    reference-named op now runs the as-coded kernel for them -- the oracle's bits."""
+    from chirrup_amd import ops
+
+    B, N, M = 5, 256, 512
+    x, q, mx, rx, my, ry = _quantised_case(B, N, M, seed=3)
+    want = oracle.mm8_seq(x, q, mx, rx, my.reshape(-1, 1), ry.reshape(-1, 1))
+    cu_ = lambda a: torch.from_numpy(a).cuda()
+
+    def off(a, k):                                    # the same values, starting k elements into a larger buffer
+        buf = torch.zeros(a.size + 16, dtype=torch.float16, device="cuda")
+        buf[k:k + a.size] = cu_(a)
+        return buf[k:k + a.size]
+
+    for which, k in (("my", 4), ("ry", 2), ("mx", 1), ("rx", 3), (None, 0)):
+        t = {"mx": cu_(mx), "rx": cu_(rx), "my": cu_(my), "ry": cu_(ry)}
+        if which:
+            t[which] = off({"mx": mx, "rx": rx, "my": my, "ry": ry}[which], k)
+            assert t[which].data_ptr() % 16 != 0
+        y = torch.empty((B, M), dtype=torch.float16, device="cuda")
+        ops.mm8_seq(B, N, M, cu_(x), cu_(q), t["mx"], t["rx"], t["my"], t["ry"], y)
+        got = y.cpu().numpy()
+        if which:
+            assert np.array_equal(bits(got), bits(want)), which              # as-coded kernel: the oracle's bits
+        else:
+            assert not np.array_equal(bits(got), bits(want))                 # aligned: the matrix-core split form (other roundings)
+            assert np.allclose(got.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=2e-3 * np.abs(want.astype(np.float32)).max())
+
+
+@pytest.mark.parametrize("shape,cdtype", [((200, 4096, 512), torch.float16), ((33, 128, 72), torch.float32),
+                                          ((3, 40, 256, 64), torch.float16), ((2, 17, 64, 48), torch.float32)])
+def test_gemm_fp16_cublas_op(shape, cdtype):
+    """torch.ops.rwkv_pip.gemm_fp16_cublas(a, b, c): c = a @ b, row-major binary16 operands, binary32 compute, binary16 or
+    binary32 c, 2-D and batched (scripts/test_mm8/gemm_fp16_cublas.cpp:29-74) -- a library pass-through, checked against
+    binary64."""
+    from chirrup_amd import ops
+
+    ops.register_torch_ops()
+    torch.manual_seed(sum(shape))
+    if len(shape) == 3:
+        m, k, n = shape
+        a, b = torch.randn(m, k, device="cuda").half(), (torch.randn(k, n, device="cuda") / k ** 0.5).half()
+        c = torch.full((m, n), float("nan"), dtype=cdtype, device="cuda")
+    else:
+        z, m, k, n = shape
+        a, b = torch.randn(z, m, k, device="cuda").half(), (torch.randn(z, k, n, device="cuda") / k ** 0.5).half()
+        c = torch.full((z, m, n), float("nan"), dtype=cdtype, device="cuda")
+    assert torch.ops.rwkv_pip.gemm_fp16_cublas(a, b, c) is None
+    ref = a.double() @ b.double()
+    tol = 2e-3 if cdtype == torch.float16 else 1e-5
+    assert bool(((c.double() - ref).abs() <= tol * ref.abs().clamp_min(1.0)).all())
+    with pytest.raises(Exception):
+        torch.ops.rwkv_pip.gemm_fp16_cublas(a.float(), b, c)
