@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
+    p.add_argument("--no-chain", action="store_true", help="LoRA up-projections as a launch of their own instead of inside the R/K/V launch, A/B only")
     p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
     p.add_argument("--lora-row-halves", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
@@ -201,6 +202,22 @@ def gemm_shape_timings(model, B):
             ops.skinny_bmm(hid, lw.lora2_t if lw.lora2_t is not None else lw.lora2, lw.lbias, splits=1, k_of=ranks, row_halves=model.lora_up_row_halves)
 
     out["lora_up"] = (_replay_time(lora_up, L), n_dn * C * 2 + B * n_dn * 2 + 4 * B * C * 2, "batched launch of the 4 LoRA up-projections, bias in the epilogue")
+    chained = (model.chain_tmix_gemms and ops.TMIX_CHAIN and B >= model.chain_min_rows and rh["rkv"] and lws[0].lora2_t is not None
+               and not gs["rkv"])
+    if chained:
+        up = torch.empty((4, B, C), dtype=torch.float16, device=dev)
+
+        def tmix_chain():
+            for lw in lws:
+                main_p = [(mixed[j], lw.rkv_t[j], rkv[j]) for j in range(3)]
+                lora_p = [(mixed[2 + j], lw.lora1[j, :ranks[j]], j, lw.lbias[j].view(-1), up[j],
+                           "tanh" if j == 1 else ("sigmoid" if j == 3 else None), ranks[j]) for j in range(4)]
+                ops.tmix_gemms(main_p, lora_p, lw.lora2_t, hid)
+
+        both = out["rkv_lora_down"][1] + out["lora_up"][1] - 2 * B * n_dn * 2     # hid is written and read inside the launch
+        out["tmix_chain"] = (_replay_time(tmix_chain, L), both,
+                             "ONE launch: R/K/V tiles + the whole LoRA chain (down-projections, activations, up-projections + bias) on the CUs R/K/V leaves idle")
+        del out["rkv_lora_down"], out["lora_up"]
     x_c, x_4c = rnd(B, C), rnd(B, 4 * C)
     pbuf = torch.empty((16, B, C), dtype=torch.float32, device=dev)
 
@@ -547,6 +564,8 @@ def main():
     if a.no_pair_reduce:
         from chirrup_amd import ops as _ops
         _ops.PAIR_REDUCE = False
+    if a.no_chain:
+        model.chain_tmix_gemms = False
     if a.row_halves_min_rows is not None:
         model.row_halves_min_rows = a.row_halves_min_rows
     if a.lora_row_halves is not None:

@@ -641,6 +641,341 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// The time-mix launch: R/K/V and the WHOLE LoRA chain of a layer (four down-projections -> tanh / sigmoid -> four up-
+// projections + bias) in ONE launch of 128-column tiles with two workgroups per tile over the two halves of the rows.
+// Round 2 ran the up-projections as a launch of their own behind the grouped R/K/V + down-projection launch: 12 us per layer
+// for 13 MB of traffic, all prologue / epilogue / launch boundary, while that grouped launch left 50 of the 256 CUs idle.
+// Here the chain runs on those CUs BESIDE the R/K/V tiles, off the critical path:
+//   workgroups [0, n_chain)   (lowest ids: dispatched first)
+//       1. one K-slice of one down-projection tile (split `dsplits` ways so that the slice is short); the slice's binary32
+//          slab goes out write-through (sc1), one lane draws the tile's ticket, the LAST slice to arrive adds the slabs in
+//          slice order (its own from LDS; sc1 loads of the others: the fence-free hand-off of MI355X_MICROARCH.md, one
+//          workgroup per CU), applies tanh / sigmoid, stores the binary16 hidden tile write-through and, after every storing
+//          wave has drained and the workgroup's barrier, adds to done[problem][half];
+//       2. a contiguous share of the up-projection tiles: ONE lane polls done[problem][half] (relaxed, s_sleep, bounded),
+//          ONE agent-scope acquire, vmcnt(0), barrier, then plain LDS-DMA loads of the hidden rows (cdna_hip_programming.md
+//          Guideline 16, recipe R1), the usual main loop and the bias epilogue;
+//       3. a `finished` ticket; the last chain workgroup zeroes the counters for the next launch.
+//   workgroups [n_chain, ...)  one R/K/V tile half each, exactly ring_gemm_kernel's EPI_F16 path; they never wait.
+// No workgroup waits for a higher-numbered one that could be undispatched behind it: the chain's producers ARE the lowest ids,
+// and every spin is bounded (status word set, outputs then undefined -- chirrup_amd checks it with the sampled ids).
+struct ChainTable {
+    const f16 *dX[4];            // down-projection inputs  [M][ldx]
+    const f16 *dW[4];            // down-projection weights [dN[p]][K], row stride ldw (rows >= dN read as zeros)
+    f16 *hid[4];                 // hidden planes [M][ld_hid]: problem p's first dN[p] columns are written
+    const void *uW[4];           // up-projection weights: tile images of [up_N][up_Kimg], the first uK[p] columns multiplied
+    const f16 *ubias[4];
+    f16 *uY[4];                  // [M][up_ldy]
+    int dN[4], dact[4], dfirst[5], uK[4];
+    int n_lora, n_chain, dsplits, ld_hid, up_N, up_Kimg, up_ldy;
+    float *slab;                 // [down tile][half][slice][16 MT][128] binary32
+    int *sync;                   // kChainTickets tickets, then kChainDone done counters, then {finished, status}
+    int spin_limit;
+    unsigned long long *stamps;  // diagnostic (skinny_gemm_clock_probe): 8 x 100-MHz time stamps per workgroup
+};
+constexpr int kChainTickets = 64, kChainDone = 8, kChainWords = kChainTickets + kChainDone + 2, kChainMaxSplits = 4;
+
+// one K-range of one 128-column tile: prologue, main loop; leaves the sums in `acc` and EVERY wave behind a barrier (the
+// ring is free again).  Loader waves come back too (ring_gemm_kernel's leave at this point).  D: ring slots.
+// chain_prologue: the loader waves' first D - 1 stages alone -- issued for the NEXT tile while the compute waves still store
+// the previous one (the up-projection share keeps its staging area apart from the ring), then chain_mainloop(.., true).
+template <int MT, int D>
+__device__ __forceinline__ void chain_stage(const Loader<false> &ld, const int kb, const int k_begin, const int n_base, unsigned char *smem) {
+    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * 128;
+    constexpr int kXRounds = (MT + 1) / 2, kWLoads = kWBytes / 16 / 256;
+    const int lw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
+    const bool short_x = (MT & 1) && lw >= 2;
+    const int k0 = k_begin + kb * kKB;
+    unsigned char *xb = smem + (kb % D) * kXBytes, *wb = smem + D * kXBytes + (kb % D) * kWBytes;
+#pragma unroll
+    for (int i = 0; i < kXRounds; i++) {
+        if (i == kXRounds - 1 && short_x) break;
+        ld.x_round(i, k0, xb + (i * 256 + lw * 64) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < kWLoads; i++) ld.w_round(n_base, i, k0, wb + (i * 256 + lw * 64) * 16);
+}
+
+template <int MT, int D>
+__device__ __forceinline__ void chain_prologue(const Tile &t, const int ldx, const int64_t ldw, const int K_img, const int k_begin,
+                                               const int nkb, const int n_base, unsigned char *smem) {
+    const Loader<false> ld(t, t.M, ldx, ldw, K_img, threadIdx.x & 255);
+#pragma unroll
+    for (int p = 0; p < D - 1; p++)
+        if (p < nkb) chain_stage<MT, D>(ld, p, k_begin, n_base, smem);
+}
+
+template <int MT, int D>
+__device__ __forceinline__ void chain_mainloop(const Tile &t, const int ldx, const int64_t ldw, const int K_img, const int k_begin,
+                                               const int nkb, const int n_base, unsigned char *smem, f32x4 (&acc)[2][MT],
+                                               const bool prologue_issued = false) {
+    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * 128;
+    constexpr int kXRounds = (MT + 1) / 2, kWLoads = kWBytes / 16 / 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const bool computes = wave < 4;
+    const int lt = tid & 255, lw = wave & 3;
+    const bool short_x = (MT & 1) && lw >= 2;
+    unsigned char *const xring = smem, *const wring = smem + D * kXBytes;
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const Loader<false> ld(t, t.M, ldx, ldw, K_img, lt);
+    if (!computes && !prologue_issued) {
+#pragma unroll
+        for (int p = 0; p < D - 1; p++)
+            if (p < nkb) chain_stage<MT, D>(ld, p, k_begin, n_base, smem);
+    }
+    for (int kb = 0; kb < nkb; kb++) {
+        if (!computes) {
+            const int left = nkb - 1 - kb, ahead = left < D - 2 ? left : (D - 2 > 0 ? D - 2 : 0);
+            if (short_x) wait_stages_ahead<kXRounds - 1 + kWLoads>(ahead);
+            else wait_stages_ahead<kXRounds + kWLoads>(ahead);
+        }
+        asm volatile("s_barrier" ::: "memory");
+        if (!computes) {
+            if (kb + D - 1 < nkb) chain_stage<MT, D>(ld, kb + D - 1, k_begin, n_base, smem);
+        } else {
+            f16x8 wf[2][2];
+            read_w_frags<false>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
+            mma_kblock<MT>(xring + (kb % D) * kXBytes, wf, c, q, acc, [] {});
+        }
+    }
+    __syncthreads();                                   // every wave: the last fragment reads are done, no LDS-DMA is pending
+}
+
+// ring slots of the up-projection share: what fits beside a staging area of its own (so that the loader waves can run ahead)
+template <int MT>
+constexpr int chain_up_depth() {
+    constexpr int slot = MT * 16 * 128 + 128 * 128, stage = MT * 16 * kLd * 4;
+    constexpr int d = (160 * 1024 - stage) / slot;
+    return d > 3 ? 3 : (d < 2 ? 2 : d);
+}
+
+__device__ __forceinline__ bool chain_wait(int *word, const int want, const int limit, int *status) {
+    for (int i = 0; i < limit; i++) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+template <int MT>
+__global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int K, const int ldx, const int64_t ldw,
+                                                         const GroupTable gt, const ChainTable ct) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const bool computes = wave < 4;
+    float *const stg = reinterpret_cast<float *>(smem);
+    int *const flag = reinterpret_cast<int *>(stg + kTileRows);          // a padding column of staged row 0
+    f32x4 acc[2][MT];
+    const int L = blockIdx.x;
+    const int m0 = MT * 16;                                               // rows of the first half
+
+    if (L >= ct.n_chain) {
+        // ---- an R/K/V tile half (ring_gemm_kernel's EPI_F16 path; the tile order is XCD-aware as tile_of_block's)
+        const int Lr = L - ct.n_chain, total = (int)gridDim.x - ct.n_chain;
+        int v = (total & 7) ? Lr : (Lr & 7) * (total >> 3) + (Lr >> 3);
+        const int half = v & 1;
+        v >>= 1;
+        if (v >= gt.first[gt.used]) return;
+        int b = 0;
+        while (b + 1 < gt.used && v >= gt.first[b + 1]) b++;
+        Tile t;
+        t.ngroup = v - gt.first[b], t.kslice = 0, t.batch = b, t.pair_id = 0;
+        t.rows0 = half ? m0 : 0;
+        t.M = half ? M - m0 : m0;
+        t.X = gt.X[b] + (int64_t)t.rows0 * ldx, t.W = gt.W[b], t.Y = gt.Y[b] + (int64_t)t.rows0 * gt.ldy[b];
+        t.bias = gt.bias[b], t.part = nullptr, t.Np = gt.N[b], t.ldy = gt.ldy[b], t.act = gt.act[b], t.w_tiled = gt.tiled[b] != 0;
+        const int n_base = t.ngroup * 128;
+        if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8] = __builtin_amdgcn_s_memrealtime();
+        chain_mainloop<MT, ring_depth<MT, false>()>(t, ldx, ldw, K, 0, K / kKB, n_base, smem, acc);
+        if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+        if (!computes) return;
+        if (n_base + wave * 32 < t.Np) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
+        __syncthreads();                               // (the four compute waves; finished waves do not count)
+        store_staged<EPI_F16, 256>(stg, t.M, n_base, t, 0, M);
+        if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+        return;
+    }
+
+    // ---- a chain workgroup
+    int *const tickets = ct.sync, *const done = ct.sync + kChainTickets, *const finished = ct.sync + kChainTickets + kChainDone;
+    int *const status = finished + 1;
+    const int n_dtiles = ct.dfirst[ct.n_lora];
+    unsigned long long *const stamps = ct.stamps ? ct.stamps + (int64_t)L * 8 : nullptr;
+    auto stamp = [&](int i) {
+        if (stamps && tid == 0) stamps[i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    // this workgroup's share of the up-projection tile halves: half-major, then column tile, problem fastest -- a contiguous share
+    // lies in one half (two at most) and mixes the problems' lengths
+    const int ctiles = (ct.up_N + 127) / 128, U = ct.n_lora * ctiles * 2, per_half = ct.n_lora * ctiles;
+    const int lo = (int)((int64_t)L * U / ct.n_chain), hi = (int)((int64_t)(L + 1) * U / ct.n_chain);
+    // Warm THIS XCD's L2 with the up-projection weights this workgroup will stream later (a few hundred KB, contiguous runs of
+    // a tile image): issued by the compute waves now, while they wait for the first stage anyway; nobody waits for the data.
+    uint32_t warm = 0;
+    if (computes) {
+        for (int it = lo; it < hi; it++) {
+            const int r = it % per_half, p = r % ct.n_lora, ctile = r / ct.n_lora;
+            const unsigned char *w0 = static_cast<const unsigned char *>(ct.uW[p]) + (int64_t)ctile * (ct.up_Kimg / kKB) * (kTileRows * kKB * 2);
+            const int lines = (ct.uK[p] / kKB) * (kTileRows * kKB * 2) / 128;
+            for (int ln = tid; ln < lines; ln += 256) warm ^= *reinterpret_cast<const uint32_t *>(w0 + (int64_t)ln * 128);     // default policy: stays in L2
+        }
+    }
+    bool ok = true;
+    if (L < n_dtiles * 2 * ct.dsplits) {
+        // 1. one K-slice of one down-projection tile half
+        const int slice = L % ct.dsplits, th = L / ct.dsplits, half = th & 1, dtile = th >> 1;
+        int p = 0;
+        while (p + 1 < ct.n_lora && dtile >= ct.dfirst[p + 1]) p++;
+        Tile t;
+        t.ngroup = dtile - ct.dfirst[p], t.kslice = slice, t.batch = p, t.pair_id = dtile * 2 + half;
+        t.rows0 = half ? m0 : 0;
+        t.M = half ? M - m0 : m0;
+        t.X = ct.dX[p] + (int64_t)t.rows0 * ldx, t.W = ct.dW[p], t.Y = ct.hid[p] + (int64_t)t.rows0 * ct.ld_hid;
+        t.bias = nullptr, t.part = nullptr, t.Np = ct.dN[p], t.ldy = ct.ld_hid, t.act = ct.dact[p], t.w_tiled = false;
+        const int n_base = t.ngroup * 128, k_slice = K / ct.dsplits;
+        chain_mainloop<MT, ring_depth<MT, false>()>(t, ldx, ldw, K, slice * k_slice, k_slice / kKB, n_base, smem, acc);
+        stamp(1);
+        if (computes && n_base + wave * 32 < t.Np) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
+        __syncthreads();
+        float *const slabs = ct.slab + (int64_t)t.pair_id * ct.dsplits * (m0 * 128);     // [slice][m0][128]
+        const int c4 = tid & 31;
+        const bool col_live = n_base + 4 * c4 < t.Np;
+        if (computes && col_live) {                    // this slice's slab, write-through
+            const __amdgpu_buffer_rsrc_t dst = make_rsrc(slabs + (int64_t)slice * (m0 * 128), (int64_t)m0 * 128 * 4);
+            for (int m = tid >> 5; m < t.M; m += 8) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(stg + m * kLd + 4 * c4);
+                __builtin_amdgcn_raw_buffer_store_b128(v, dst, (m * 128 + 4 * c4) * 4, 0, 16);      // aux 16 = sc1
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {                                // arrive, then wait for the other K-slices of this tile half (bounded)
+            __hip_atomic_fetch_add(tickets + t.pair_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = chain_wait(tickets + t.pair_id, ct.dsplits, ct.spin_limit, status);
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the loads below the barrier)
+        stamp(2);
+        ok = *flag != 0;
+        if (ok) {
+            // EVERY slice combines its share of the rows (rows slice * rq ...), all eight waves, one row x 8 columns per lane:
+            // hidden = act(binary16(sum of the slices in slice order)) -- its own slice from LDS, the others by sc1 loads, all of
+            // them in flight before the first add (a lone last arriver took 15 us for the same 172 KB: per-CU load latency under
+            // the R/K/V tiles' streaming is ~6 us a round) -- stored write-through, 16 B per lane
+            const int c8 = tid & 15, n = n_base + 8 * c8;
+            const int rq = (t.M + ct.dsplits - 1) / ct.dsplits, r_end = (slice + 1) * rq < t.M ? (slice + 1) * rq : t.M;
+            if (n < t.Np) {
+                const __amdgpu_buffer_rsrc_t src = make_rsrc(slabs, (int64_t)ct.dsplits * m0 * 128 * 4);
+                const __amdgpu_buffer_rsrc_t out = make_rsrc(t.Y, ((int64_t)(t.M - 1) * ct.ld_hid + t.Np) * 2);
+                for (int m = slice * rq + (tid >> 4); m < r_end; m += 32) {
+                    f32x4 oth[kChainMaxSplits][2];
+#pragma unroll
+                    for (int k = 0; k < kChainMaxSplits; k++)
+                        if (k < ct.dsplits && k != slice) {
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                                oth[k][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((k * m0 + m) * 128 + 8 * c8 + 4 * h) * 4, 0, 16));
+                        }
+                    f32x4 sum[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                    for (int k = 0; k < kChainMaxSplits; k++)
+                        if (k < ct.dsplits) {
+#pragma unroll
+                            for (int h = 0; h < 2; h++)
+                                sum[h] += (k == slice) ? *reinterpret_cast<const f32x4 *>(stg + m * kLd + 8 * c8 + 4 * h) : oth[k][h];
+                        }
+                    f16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) o[e] = (f16)apply_act(e < 4 ? sum[0][e] : sum[1][e - 4], t.act);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out, (m * ct.ld_hid + n) * 2, 0, 16);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains ...
+            __syncthreads();                                        // ... before ONE lane signals for all of them
+            if (tid == 0) __hip_atomic_fetch_add(done + p * 2 + half, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();                                            // the staging area is free again
+        stamp(3);
+    }
+    // 2. the up-projection share; ONE wait on all of a half's counters and ONE acquire when the share first touches that half.
+    //    The ring is shallower here (tiles of 2..8 K-blocks) and the staging area lies behind it, so the loader waves issue the
+    //    NEXT tile's first stages while the compute waves still store this one.
+    {
+        constexpr int DU = chain_up_depth<MT>();
+        float *const stgu = reinterpret_cast<float *>(smem + DU * (MT * 16 * 128 + 128 * 128));
+        auto up_tile = [&](int it, Tile &t, int &nkb, int &n_base) {
+            const int half = it / per_half, r = it % per_half, p = r % ct.n_lora, ctile = r / ct.n_lora;
+            t.ngroup = ctile, t.kslice = 0, t.batch = p, t.pair_id = 0;
+            t.rows0 = half ? m0 : 0;
+            t.M = half ? M - m0 : m0;
+            t.X = ct.hid[p] + (int64_t)t.rows0 * ct.ld_hid, t.W = ct.uW[p], t.Y = ct.uY[p] + (int64_t)t.rows0 * ct.up_ldy;
+            t.bias = ct.ubias[p], t.part = nullptr, t.Np = ct.up_N, t.ldy = ct.up_ldy, t.act = 0, t.w_tiled = true;
+            nkb = ct.uK[p] / kKB, n_base = ctile * 128;
+        };
+        int have = 0;                                               // halves already acquired (bit per half)
+        bool pre = false;                                           // the ring already holds the first stages of tile `it`
+        for (int it = lo; it < hi && ok; it++) {
+            const int half = it / per_half;
+            if (!((have >> half) & 1)) {                            // (never with pre: a tile is only run ahead inside an acquired half)
+                if (tid == 0) {
+                    bool got = true;
+                    for (int pp = 0; pp < ct.n_lora && got; pp++)
+                        got = chain_wait(done + pp * 2 + half, (ct.dfirst[pp + 1] - ct.dfirst[pp]) * ct.dsplits, ct.spin_limit, status);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    *flag = got;
+                }
+                __syncthreads();
+                ok = *flag != 0;
+                __syncthreads();                                    // (flag lies in the ring: rewritten by the stages below)
+                if (!ok) break;
+                have |= 1 << half;
+                stamp(4);
+            }
+            Tile t;
+            int nkb, n_base;
+            up_tile(it, t, nkb, n_base);
+            chain_mainloop<MT, DU>(t, ct.ld_hid, ct.up_Kimg, ct.up_Kimg, 0, nkb, n_base, smem, acc, pre);
+            pre = false;
+            if (it + 1 < hi && ((have >> ((it + 1) / per_half)) & 1)) {
+                pre = true;
+                if (!computes) {
+                    Tile tn;
+                    int nkb_n, n_base_n;
+                    up_tile(it + 1, tn, nkb_n, n_base_n);
+                    chain_prologue<MT, DU>(tn, ct.ld_hid, ct.up_Kimg, ct.up_Kimg, 0, nkb_n, n_base_n, smem);
+                }
+            }
+            if (computes && n_base + wave * 32 < t.Np) stage_acc<MT>(stgu, acc, t.M, wave * 32, c, q);
+            __syncthreads();
+            if (computes) store_staged<EPI_F16, 256>(stgu, t.M, n_base, t, 0, M);
+            // (no barrier here: the next tile's main loop has at least two before anybody writes the staging area again)
+            if (it == lo) stamp(5);
+        }
+        stamp(6);
+    }
+    if (warm == 0x9e3779b9u && (uint32_t)tid == 511u + warm) __hip_atomic_store(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (never: keeps the warm-up loads)
+    // 3. the last chain workgroup to finish leaves every counter at zero for the next launch
+    stamp(7);
+    if (tid == 0) {
+        const int f = __hip_atomic_fetch_add(finished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (f == ct.n_chain - 1) {
+            for (int i = 0; i < kChainTickets; i++) __hip_atomic_store(tickets + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < kChainDone; i++) __hip_atomic_store(done + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(finished, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // BN = 256: eight compute waves (two per SIMD).  Waves 0-3 issue the x loads (next K-block, 2 slots) at the start of an
 // iteration, waves 4-7 the W loads (WD-1 K-blocks ahead, WD slots) between the two k-steps of their MFMAs.
 template <int MT, bool W8, int EPI>
@@ -1305,6 +1640,108 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
     bool wide = true;
     for (int i = 0; i < count; i++) wide = wide && wide_ok(gt.N[i], gt.ldy[i], gt.Y[i]);
     return launch_reduce(wide, count, st, M, max_n, s, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, gt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R/K/V + the whole LoRA chain of one RWKV-7 layer in ONE launch (chain_gemm_kernel; rwkv7.py:625-630, :637).
+//   main[i]  (i < n_main <= 4): y_i = x_i . w_i^T   (w tile-image, or row-major with row stride ldw)          [M][n_i]
+//   lora[p]  (p < n_lora <= 4): hid_p = act_p(x_p . wd_p^T)  [M][n_p of ld_hid],  y_p = hid_p[:, :k_up_p] . wu_p^T + bias_p  [M][up_n]
+// All x share M (33..256 rows), K and ldx; wd_p row-major [n_p][K] with row stride ldw (n_p % 64 == 0, rows past n_p of a
+// 128-row tile read as zeros); wu_p tile images of [up_n][up_kimg] (k_up_p <= up_kimg, both % 64 == 0; up_n % 128 == 0).
+// workspace: rwkv7_tmix_gemms_workspace_bytes(...) bytes of hipMalloc'ed memory; sync: rwkv7_tmix_sync_words() ints, ZERO before the
+// first use, zero again after every completed launch (a launch that did not complete: zero them yourself); used by one
+// launch at a time.  sync[rwkv7_tmix_sync_words() - 1] is a STATUS word: non-zero after a launch whose bounded waits gave up
+// (another tenant holding most of the chip for > spin budget): that launch's LoRA outputs are then undefined.
+extern "C" int rwkv7_tmix_sync_words(void) { return kChainWords; }
+
+namespace {
+int chain_dsplits(int K) {
+    const int kb = K / kKB;
+    if (kb % 4 == 0 && kb / 4 >= 4) return 4;
+    if (kb % 2 == 0 && kb / 2 >= 4) return 2;
+    return 1;
+}
+}  // namespace
+
+extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_lora, const chirrup_lora_problem *lora) {
+    if (M <= 0 || K <= 0 || (K % kKB) || n_lora <= 0 || n_lora > 4 || !lora) return 0;
+    int tiles = 0;
+    for (int p = 0; p < n_lora; p++) tiles += (lora[p].n + kTileRows - 1) / kTileRows;
+    const int MT = tiles_of(M, true);
+    return (int64_t)tiles * 2 * chain_dsplits(K) * (MT * 16) * kTileRows * (int64_t)sizeof(float);
+}
+
+extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
+                                const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, void *workspace,
+                                void *sync, int spin_limit, void *stream) {
+    if (n_main <= 0 || n_main > 4 || n_lora <= 0 || n_lora > 4 || !main_p || !lora) return CHIRRUP_E_SHAPE;
+    if (M <= 32 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7)) return CHIRRUP_E_SHAPE;
+    if (up_n <= 0 || (up_n % kTileRows) || up_kimg <= 0 || (up_kimg % kKB) || up_ldy < up_n || (up_ldy & 3) || ld_hid < up_kimg || (ld_hid & 7))
+        return CHIRRUP_E_SHAPE;
+    if (!workspace || !sync) return CHIRRUP_E_NULL;
+    if (mis16(workspace) || (reinterpret_cast<uintptr_t>(sync) & 15)) return CHIRRUP_E_ALIGN;
+    GroupTable gt{};
+    gt.used = n_main;
+    for (int i = 0; i < n_main; i++) {
+        const chirrup_gemm_problem &q = main_p[i];
+        if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
+        if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
+        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7) || (reinterpret_cast<uintptr_t>(q.bias) & 7)) return CHIRRUP_E_ALIGN;
+        if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+        gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y), gt.bias[i] = static_cast<const f16 *>(q.bias);
+        gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act, gt.tiled[i] = q.w_tiled ? 1 : 0;
+        gt.first[i + 1] = gt.first[i] + (q.n + kTileRows - 1) / kTileRows;
+    }
+    ChainTable ct{};
+    ct.n_lora = n_lora, ct.dsplits = chain_dsplits(K), ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
+    for (int p = 0; p < n_lora; p++) {
+        const chirrup_lora_problem &q = lora[p];
+        if (q.n <= 0 || (q.n % kKB) || q.n > ld_hid || q.k_up <= 0 || (q.k_up % kKB) || q.k_up > q.n || q.k_up > up_kimg || q.act < 0 || q.act > 3)
+            return CHIRRUP_E_SHAPE;
+        if (!q.x || !q.w || !q.hid || !q.w_up || !q.y) return CHIRRUP_E_NULL;
+        if (mis16(q.x) || mis16(q.w) || mis16(q.hid) || mis16(q.w_up) || (reinterpret_cast<uintptr_t>(q.y) & 7) || (reinterpret_cast<uintptr_t>(q.bias) & 7))
+            return CHIRRUP_E_ALIGN;
+        ct.dX[p] = static_cast<const f16 *>(q.x), ct.dW[p] = static_cast<const f16 *>(q.w), ct.hid[p] = static_cast<f16 *>(q.hid);
+        ct.uW[p] = q.w_up, ct.ubias[p] = static_cast<const f16 *>(q.bias), ct.uY[p] = static_cast<f16 *>(q.y);
+        ct.dN[p] = q.n, ct.dact[p] = q.act, ct.uK[p] = q.k_up;
+        ct.dfirst[p + 1] = ct.dfirst[p] + (q.n + kTileRows - 1) / kTileRows;
+    }
+    const int n_dtiles = ct.dfirst[n_lora];
+    if (n_dtiles * 2 > kChainTickets) return CHIRRUP_E_UNSUPPORTED;
+    const int main_wgs = (gt.first[n_main] * 2 + 15) / 16 * 16;     // two halves per tile; whole runs of the XCD-aware tile order
+    ct.n_chain = (n_dtiles * 2 * ct.dsplits + 7) / 8 * 8;           // the down-projection slices ...
+    const int spare = (256 - main_wgs) / 8 * 8;                      // ... and every CU the R/K/V tiles leave idle, for the up-projections
+    if (spare > ct.n_chain) ct.n_chain = spare < 96 ? spare : 96;
+    ct.slab = static_cast<float *>(workspace), ct.sync = static_cast<int *>(sync);
+    ct.spin_limit = spin_limit > 0 ? spin_limit : 400000;          // x ~0.25 us of s_sleep: ~0.1 s
+    const dim3 grid(ct.n_chain + main_wgs);
+    ct.stamps = (g_clock_probe && g_clock_pairs >= (int)grid.x * 4) ? g_clock_probe : nullptr;
+    const int MT = tiles_of(M, true);
+    const size_t lds = lds_bytes(128, MT, false);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define CHAIN_GO(MTV)                                                                                                          \
+    do {                                                                                                                       \
+        auto kern = chain_gemm_kernel<MTV>;                                                                                    \
+        static std::atomic<bool> lds_limit_raised[32];                                                                         \
+        int dev_ = 0;                                                                                                          \
+        (void)hipGetDevice(&dev_);                                                                                             \
+        if (!lds_limit_raised[dev_ & 31].load(std::memory_order_acquire)) {                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            lds_limit_raised[dev_ & 31].store(true, std::memory_order_release);                                                \
+        }                                                                                                                      \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, K, ldx, ldw, gt, ct);                                            \
+    } while (0)
+    switch (MT) {
+        case 2: CHAIN_GO(2); break;
+        case 3: CHAIN_GO(3); break;
+        case 4: CHAIN_GO(4); break;
+        case 5: CHAIN_GO(5); break;
+        case 6: CHAIN_GO(6); break;
+        case 7: CHAIN_GO(7); break;
+        default: CHAIN_GO(8); break;
+    }
+#undef CHAIN_GO
+    return (int)hipGetLastError();
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,

@@ -57,14 +57,21 @@ class AsyncEngineCore:
     LOAD_TIMEOUT_S = 300
 
     def __init__(self, worker_factory: Optional[Callable[..., Any]] = None, tokenizer=None, worker_mode: str = "thread",
-                 worker_kwargs: Optional[Dict[str, Any]] = None):
+                 worker_kwargs: Optional[Dict[str, Any]] = None, state_arena_rows: int = 0, prefix_affinity: bool = True,
+                 gpu_ids: Optional[List[int]] = None):
         """worker_factory(**worker_args) -> object with .start(): defaults to chirrup_amd.worker.Worker; in process mode it is
         called INSIDE the worker process and must be picklable (a module-level function).  worker_kwargs: extra Worker
-        arguments (e.g. run_ahead)."""
+        arguments (e.g. run_ahead).  state_arena_rows (process mode): rows of the HBM prefix-state arena EVERY worker process
+        builds on its GPU; ``self.state_arena`` is then the engine-side view to hand to ``SimpleStateCache(arena=...)`` -- prefix
+        states never leave HBM (chirrup_amd/remote_arena.py).  prefix_affinity=False queues hits on the shared queue instead of
+        the owning worker's (tests: every hit may then be installed through another process's IPC handle).  gpu_ids: device of
+        worker k (default k)."""
         if worker_mode not in ("thread", "process", "auto"):
             raise ValueError("worker_mode must be 'thread', 'process' or 'auto'")
         self.worker_mode = worker_mode
         self._worker_kwargs = dict(worker_kwargs or {})
+        self.state_arena_rows, self.prefix_affinity, self.gpu_ids = int(state_arena_rows), prefix_affinity, gpu_ids
+        self.state_arena = None                       # process mode with state_arena_rows > 0: a remote_arena.RemoteArena
         self._router = None
         self._monitor = None
         self._result_q = None
@@ -97,13 +104,25 @@ class AsyncEngineCore:
         from . import engine_process as ep
 
         self._result_q, mp_task_q = ep.make_queues()
-        self._router = ep.ResultRouter(self._result_q, self.worker_event_queue, self._on_process_worker_exit)
-        self.task_queue = ep.ProcessTaskQueue(mp_task_q, self._router)
-        self.workers = ep.spawn_workers(worker_num, model_config, batch_size, self._worker_factory, self._worker_kwargs,
-                                        self._result_q, mp_task_q)
+        kwargs = dict(self._worker_kwargs)
+        if self.state_arena_rows > 0:
+            from .remote_arena import RemoteArena
+
+            kwargs["state_arena_rows"] = self.state_arena_rows
+            self.state_arena = RemoteArena(self.state_arena_rows, worker_num, self._send_arena_free)
+        self._router = ep.ResultRouter(self._result_q, self.worker_event_queue, self._on_process_worker_exit, self.state_arena)
+        self.workers, affinity_qs = ep.spawn_workers(worker_num, model_config, batch_size, self._worker_factory, kwargs,
+                                                     self._result_q, mp_task_q, self.gpu_ids)
+        self.task_queue = ep.ProcessTaskQueue(mp_task_q, self._router, affinity_qs, self.prefix_affinity)
         self._router.start()
         self._monitor = ep.LivenessMonitor(self.workers, self._result_q, lambda: self.is_shutdown)
         self._monitor.start()
+
+    def _send_arena_free(self, worker_id: str, row: int) -> None:
+        """RemoteArena: the cache has dropped a prefix and no hit on it is in flight -- its worker may reuse the row."""
+        for w in self.workers:
+            if w.worker_id == worker_id and w.is_alive():
+                w.control_q.put({"type": "arena_free", "row": int(row)})
 
     def _on_process_worker_exit(self, worker_id: str, kind: str) -> None:
         """Router thread: a worker process reported an error or ended -- by its own message, or, for a hard exit (HIP abort,

@@ -13,8 +13,11 @@ engine and the workers are replaced by adapters over ``multiprocessing`` queues:
     AbortChannel.put_nowait(("abort", ..)) - task ids --->  abort listener -> the task's local task_event_queue
     control queue  ---------- {"type": "shutdown"} ------>  ControlQueue.get_nowait()
 
-Prefix states cross the process boundary as host tensors (torch's shared-memory pickling): a worker in this mode exports
-with ``state_cache_device="cpu"``; an HBM-resident arena needs the workers in the engine's own process (thread mode).
+Prefix states: with ``state_arena_rows > 0`` (``AsyncEngineCore(..., state_arena_rows=N)``) every worker process owns an
+``HbmStateArena`` on its GPU and only row ADDRESSES cross the process boundary -- export, cache, hit and install without a
+state byte on the host; a hit is queued for the worker that owns the row (affinity) and an idle worker that takes it instead
+copies the row out of the owner's arena through a HIP IPC handle (chirrup_amd/remote_arena.py).  Without it a worker exports
+with ``state_cache_device="cpu"`` and states travel as host tensors (torch's shared-memory pickling), as in round 2.
 """
 import multiprocessing as mp
 import multiprocessing.connection
@@ -24,6 +27,7 @@ from collections import OrderedDict
 from typing import Any, Callable, Dict, List, Optional
 
 from .core_structure import ModelLoadConfig, RequestStatus, Task
+from .remote_arena import WIRE_KEY, PeerArenas, RemoteStateRef, is_wire_row
 
 _TASK_FIELDS = ("prompt_str", "prefill_tokens", "state", "task_id", "priority", "temperature", "top_p", "top_k", "presence_penalty",
                 "frequency_penalty", "penalty_decay", "max_tokens", "stop_tokens", "forbidden_tokens", "cache_prefill",
@@ -33,6 +37,9 @@ _RESULT_FIELDS = ("request_status", "generated_tokens", "decoded_texts", "prefil
 
 def task_to_wire(task: Task) -> Dict[str, Any]:
     d = {k: getattr(task, k) for k in _TASK_FIELDS}
+    if isinstance(d["state"], RemoteStateRef):                           # a row of a worker's arena: its address travels, the
+        d["state"] = d["state"].wire()                                   # handle stays pinned in the router until it is installed
+        return d
     if d["state"] is not None and hasattr(d["state"], "tensors"):       # an ArenaRef cannot leave its process: ship copies
         ref, d["state"] = d["state"], d["state"].tensors()
         ref.release()
@@ -45,8 +52,8 @@ def task_to_wire(task: Task) -> Dict[str, Any]:
 class ResultSink:
     """What a Task's ``output_queue`` is inside a worker process."""
 
-    def __init__(self, result_q, task_id: str, on_done=None):
-        self._q, self._id, self._on_done = result_q, task_id, on_done
+    def __init__(self, result_q, task_id: str, on_done=None, worker_id: Optional[str] = None, arena=None):
+        self._q, self._id, self._on_done, self._wid, self._arena = result_q, task_id, on_done, worker_id, arena
 
     def put_nowait(self, msg):
         kind, payload = msg
@@ -54,6 +61,11 @@ class ResultSink:
             payload = {k: (int(getattr(payload, k)) if k == "request_status" else getattr(payload, k)) for k in _RESULT_FIELDS}
             if self._on_done is not None:
                 self._on_done(self._id)
+        elif kind == "cache_prefill" and self._arena is not None and getattr(payload["state"], "arena", None) is self._arena:
+            # exported straight into a row of THIS worker's arena: the row now belongs to whoever caches the prefix in the
+            # engine process (freed by an {"type": "arena_free"} control message); only its address leaves the process
+            row = self._arena.adopt(payload["state"])
+            payload = {"state": {WIRE_KEY: (self._wid, row)}, "prefilled_tokens": tuple(payload["prefilled_tokens"])}
         elif kind == "cache_prefill":
             st = payload["state"]
             if hasattr(st, "tensors"):
@@ -89,14 +101,41 @@ class RemoteTaskQueue:
 
     EARLY_ABORTS = 4096                                 # ids remembered for tasks nobody has pulled yet (oldest dropped first)
 
-    def __init__(self, task_q, result_q, worker_id: str):
+    def __init__(self, task_q, result_q, worker_id: str, affinity_qs: Optional[Dict[str, Any]] = None):
         self._q, self._result_q, self._wid = task_q, result_q, worker_id
+        self._affinity = dict(affinity_qs or {})        # worker id -> queue of hits on rows of that worker's arena
+        self.arena = None                               # set by the worker once it has built its arena
         self.local_events: Dict[str, queue.Queue] = {}
         self._early_aborts: "OrderedDict[str, None]" = OrderedDict()
         self._lock = threading.Lock()
 
+    def _pull(self) -> Dict[str, Any]:
+        """Hits on this worker's own rows first (one local copy), then the shared queue, then -- rather than idling -- hits
+        queued for another worker (their rows are read through its IPC handle)."""
+        mine = self._affinity.get(self._wid)
+        if mine is not None:
+            try:
+                return mine.get_nowait()
+            except queue.Empty:
+                pass
+        try:
+            return self._q.get_nowait()
+        except queue.Empty:
+            pass
+        for wid, q_ in self._affinity.items():
+            if wid != self._wid:
+                try:
+                    return q_.get_nowait()
+                except queue.Empty:
+                    pass
+        raise queue.Empty
+
+    def installed(self, task_id: str, peer: bool) -> None:
+        """The copy of an arena row into this worker's slot has completed: the engine may let the row go."""
+        self._result_q.put((task_id, ("__installed__", {"peer": bool(peer), "worker": self._wid})))
+
     def get_nowait(self) -> Task:
-        d = self._q.get_nowait()                        # queue.Empty when there is nothing to pull
+        d = self._pull()                                # queue.Empty when there is nothing to pull
         ev = queue.Queue()
         with self._lock:
             self.local_events[d["task_id"]] = ev
@@ -106,7 +145,8 @@ class RemoteTaskQueue:
             if self._early_aborts.pop(d["task_id"], 0) is None:
                 ev.put_nowait(("abort", None))
         self._result_q.put((d["task_id"], ("__accepted__", self._wid)))
-        return Task(output_queue=ResultSink(self._result_q, d["task_id"], on_done=self.forget), task_event_queue=ev, **d)
+        return Task(output_queue=ResultSink(self._result_q, d["task_id"], on_done=self.forget, worker_id=self._wid, arena=self.arena),
+                    task_event_queue=ev, **d)
 
     def deliver_abort(self, task_id: str) -> None:
         with self._lock:
@@ -125,9 +165,15 @@ class RemoteTaskQueue:
 
 
 def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, batch_size: int, task_q, result_q,
-                        control_q, abort_q, worker_factory: Optional[Callable[..., Any]], worker_kwargs: Dict[str, Any]) -> None:
+                        control_q, abort_q, worker_factory: Optional[Callable[..., Any]], worker_kwargs: Dict[str, Any],
+                        affinity_qs: Optional[Dict[str, Any]] = None, peer_qs: Optional[Dict[str, Any]] = None) -> None:
     """Entry point of a worker process (spawned: nothing of the parent's CUDA/HIP state is inherited)."""
-    tasks = RemoteTaskQueue(task_q, result_q, worker_id)
+    tasks = RemoteTaskQueue(task_q, result_q, worker_id, affinity_qs)
+    worker_kwargs = dict(worker_kwargs)
+    if worker_kwargs.get("state_arena_rows", 0) > 0 and peer_qs:
+        import torch.multiprocessing  # noqa: F401 -- registers the tensor reductions (IPC handles) with multiprocessing's pickler
+
+        worker_kwargs["peer_arenas"] = PeerArenas(worker_id, peer_qs[worker_id], peer_qs)
 
     def listen():
         while True:
@@ -176,12 +222,19 @@ class AbortChannel:
 class ProcessTaskQueue:
     """task_queue of the engine in process mode: registers the request's result channel, ships the task."""
 
-    def __init__(self, task_q, router: "ResultRouter"):
-        self._q, self._router = task_q, router
+    def __init__(self, task_q, router: "ResultRouter", affinity_qs: Optional[Dict[str, Any]] = None, prefix_affinity: bool = True):
+        self._q, self._router, self._affinity, self.prefix_affinity = task_q, router, dict(affinity_qs or {}), prefix_affinity
 
     def put_nowait(self, task: Task):
         self._router.register(task)
-        self._q.put(task_to_wire(task))
+        wire = task_to_wire(task)
+        if isinstance(task.state, RemoteStateRef):
+            self._router.pin(task.task_id, task.state)   # released on "__installed__" (or when the task ends)
+            q_ = self._affinity.get(task.state.worker_id) if self.prefix_affinity else None
+            if q_ is not None:                           # the worker whose arena holds the row pulls it first
+                q_.put(wire)
+                return
+        self._q.put(wire)
 
     def get_nowait(self):                               # (used when the last worker died: drain what nobody will pull)
         return self._q.get_nowait()
@@ -190,12 +243,25 @@ class ProcessTaskQueue:
 class ResultRouter(threading.Thread):
     """Moves worker messages from the shared result queue to the asyncio-side channels of their requests."""
 
-    def __init__(self, result_q, worker_event_queue, on_worker_exit):
+    def __init__(self, result_q, worker_event_queue, on_worker_exit, remote_arena=None):
         super().__init__(daemon=True, name="chirrup:router")
         self._q, self._events, self._on_exit = result_q, worker_event_queue, on_worker_exit
         self._tasks: Dict[str, Task] = {}
         self.owner: Dict[str, str] = {}                 # task id -> worker id, once pulled
         self._lock = threading.Lock()
+        self.remote_arena = remote_arena
+        self._pinned: Dict[str, RemoteStateRef] = {}    # task id -> the arena row its request starts from, until installed
+        self.installs = {"local": 0, "peer": 0}         # arena rows installed by their own worker / by another one (IPC)
+
+    def pin(self, task_id: str, ref: RemoteStateRef) -> None:
+        with self._lock:
+            self._pinned[task_id] = ref
+
+    def _unpin(self, task_id: str) -> None:
+        with self._lock:
+            ref = self._pinned.pop(task_id, None)
+        if ref is not None:
+            ref.release()
 
     def register(self, task: Task) -> None:
         with self._lock:
@@ -211,6 +277,7 @@ class ResultRouter(threading.Thread):
 
     def finish_aborted(self, task: Task) -> None:
         task.request_status = RequestStatus.FINISHED_ABORTED
+        self._unpin(task.task_id)
         with self._lock:
             self._tasks.pop(task.task_id, None)
             self.owner.pop(task.task_id, None)
@@ -238,8 +305,17 @@ class ResultRouter(threading.Thread):
                 if kind == "task_completed":
                     self._tasks.pop(tid, None)
                     self.owner.pop(tid, None)
+            if kind == "__installed__":
+                self.installs["peer" if payload.get("peer") else "local"] += 1
+                self._unpin(tid)
+                continue
+            if kind == "task_completed":
+                self._unpin(tid)                        # (a request that ended before its row was installed)
             if task is None:
                 continue
+            if kind == "cache_prefill" and is_wire_row(payload.get("state")) and self.remote_arena is not None:
+                wid, row = payload["state"][WIRE_KEY]
+                payload = {"state": self.remote_arena.incoming(wid, row), "prefilled_tokens": payload["prefilled_tokens"]}
             if kind == "task_completed":
                 task.request_status = RequestStatus(payload["request_status"])
                 task.generated_tokens, task.decoded_texts = payload["generated_tokens"], payload["decoded_texts"]
@@ -294,19 +370,28 @@ class LivenessMonitor(threading.Thread):
                 self._q.put(("__worker_event__", (h.worker_id, "worker_exit", {})))
 
 
-def spawn_workers(worker_num: int, model_config: ModelLoadConfig, batch_size: int, worker_factory, worker_kwargs, result_q, task_q):
+def spawn_workers(worker_num: int, model_config: ModelLoadConfig, batch_size: int, worker_factory, worker_kwargs, result_q, task_q,
+                  gpu_ids: Optional[List[int]] = None):
     """Start one process per GPU with the ``spawn`` method (a forked child of a process that has initialised HIP is not
-    usable, and the parent must not have to).  Returns the handles."""
+    usable, and the parent must not have to).  Returns (handles, affinity queues by worker id).  gpu_ids: device of worker k
+    (default k; rehearsals put several workers on one GPU)."""
     ctx = mp.get_context("spawn")
+    wids = [f"worker_{k}" for k in range(worker_num)]
+    arena_mode = worker_kwargs.get("state_arena_rows", 0) > 0
+    affinity_qs = {wid: ctx.Queue() for wid in wids} if arena_mode else {}
+    peer_qs = {wid: ctx.Queue() for wid in wids} if arena_mode else {}
     handles = []
-    for k in range(worker_num):
-        wid = f"worker_{k}"
+    for k, wid in enumerate(wids):
+        gpu = [gpu_ids[k] if gpu_ids is not None else k]
         control_q, abort_q = ctx.Queue(), ctx.Queue()
         p = ctx.Process(target=worker_process_main, name=f"chirrup:{wid}", daemon=True,
-                        args=(wid, [k], model_config, batch_size, task_q, result_q, control_q, abort_q, worker_factory, worker_kwargs))
+                        args=(wid, gpu, model_config, batch_size, task_q, result_q, control_q, abort_q, worker_factory, worker_kwargs,
+                              affinity_qs, peer_qs))
         p.start()
-        handles.append(ProcessWorkerHandle(wid, [k], p, control_q, abort_q))
-    return handles
+        h = ProcessWorkerHandle(wid, gpu, p, control_q, abort_q)
+        h.keep = (affinity_qs, peer_qs)          # the parent must hold every queue it handed over: with the spawn method a queue's
+        handles.append(h)                        # semaphores are unlinked when the parent's object dies, possibly before the child opens them
+    return handles, affinity_qs
 
 
 def make_queues():

@@ -579,6 +579,96 @@ def skinny_group(problems, splits: int = 0, row_halves: bool = False):
     _check_gemm(rc, "skinny_gemm_f16_group", x0.device)
 
 
+class _LoraProblem(ctypes.Structure):
+    """chirrup_lora_problem of include/chirrup_amd.h"""
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("hid", ctypes.c_void_p), ("w_up", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("y", ctypes.c_void_p), ("n", ctypes.c_int), ("k_up", ctypes.c_int), ("act", ctypes.c_int)]
+
+
+_chain_sync = {}
+_chain_ws = {}
+TMIX_CHAIN = True          # False: R/K/V + LoRA-down as the grouped launch and the up-projections as a launch of their own (A/B)
+
+
+def _chain_state(device, nbytes: int):
+    """(slab workspace, sync words) of the current stream: one time-mix launch at a time per stream, which stream order gives."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    sync = _chain_sync.get(key)
+    if sync is None:
+        sync = _chain_sync[key] = torch.zeros(_lib.load().rwkv7_tmix_sync_words() + 2, dtype=torch.int32, device=device)
+    ws = _chain_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _chain_ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    return ws, sync
+
+
+def reset_chain_sync(device=None) -> None:
+    """Zero the hand-off words of the current stream's time-mix launches (a memset node when the stream is capturing)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _chain_sync:
+        _chain_state(dev, 0)
+    _chain_sync[key].zero_()
+
+
+def chain_status() -> int:
+    """Non-zero when a bounded wait of any time-mix launch of this process gave up (its LoRA outputs were undefined)."""
+    n = _lib.load().rwkv7_tmix_sync_words()
+    return int(sum(int(t[n - 1]) for t in _chain_sync.values()))
+
+
+def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, spin_limit: int = 0) -> None:
+    """R/K/V and the whole LoRA chain of a layer in ONE launch (include/chirrup_amd.h: rwkv7_tmix_gemms).
+    main: list of (x [M,K], weight [N,K] or TiledWeight, out [M,N]);
+    lora: list of (x [M,K], w_down [n,K] row-major, plane index z into hid / up_weight, bias [C] or None, out [M,C], act, k_up);
+    hid [Z, M, ld_hid] fp16 scratch; up_weight: tile images of [Z, C, ld_hid]."""
+    x0 = main[0][0]
+    M, K = x0.shape
+    L = _lib.load()
+    marr = (_GemmProblem * len(main))()
+    ldw = None
+    for i, (x, w, out) in enumerate(main):
+        N, wptr, ldw_i, w_tiled = _weight_args(w, K)
+        if not w_tiled:
+            ldw = ldw_i if ldw is None else ldw
+            if ldw_i != ldw:
+                raise _lib.ChirrupAmdError("tmix_gemms: row-major weights must share their row stride")
+        if tuple(x.shape) != (M, K) or x.stride(0) != x0.stride(0) or tuple(out.shape) != (M, N) or x.dtype != torch.float16:
+            raise _lib.ChirrupAmdError("tmix_gemms: problems must share M, K and the row stride of x")
+        marr[i] = _GemmProblem(x.data_ptr(), wptr, out.data_ptr(), None, N, out.stride(0), 0, w_tiled)
+    Z, up_n, up_k = up_weight.shape
+    if hid.dim() != 3 or hid.shape[1] != M or hid.shape[2] < up_k or hid.dtype != torch.float16 or not hid.is_contiguous():
+        raise _lib.ChirrupAmdError("hid: expected contiguous fp16 [Z, M, >= up_kimg]")
+    larr = (_LoraProblem * len(lora))()
+    for i, (x, wd, z, bias, out, act, k_up) in enumerate(lora):
+        n = wd.shape[0]
+        if wd.dim() != 2 or wd.shape[1] != K or wd.stride(1) != 1 or wd.dtype != torch.float16:
+            raise _lib.ChirrupAmdError("w_down: expected fp16 [n, K] with unit inner stride")
+        ldw = wd.stride(0) if ldw is None else ldw
+        if wd.stride(0) != ldw:
+            raise _lib.ChirrupAmdError("tmix_gemms: row-major weights must share their row stride")
+        if tuple(x.shape) != (M, K) or x.stride(0) != x0.stride(0) or tuple(out.shape) != (M, up_n) or out.stride(1) != 1:
+            raise _lib.ChirrupAmdError("tmix_gemms: LoRA problems must share M, K, the row stride of x; out [M, up_n]")
+        if bias is not None:
+            _chk16("bias", bias, up_n)
+        larr[i] = _LoraProblem(x.data_ptr(), wd.data_ptr(), hid[z].data_ptr(), up_weight.data[z].data_ptr(), _ptr(bias) or None,
+                               out.data_ptr(), n, int(k_up), _GROUP_ACTS[act])
+    up_ldy = lora[0][4].stride(0)
+    if any(p[4].stride(0) != up_ldy for p in lora):
+        raise _lib.ChirrupAmdError("tmix_gemms: the up-projection outputs must share their row stride")
+    nbytes = L.rwkv7_tmix_gemms_workspace_bytes(M, K, len(lora), ctypes.addressof(larr))
+    ws, sync = _chain_state(x0.device, nbytes + 256)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    rc = L.rwkv7_tmix_gemms(M, K, x0.stride(0), ldw if ldw is not None else K, len(main), ctypes.addressof(marr), len(lora),
+                            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, base, sync.data_ptr(), spin_limit, _stream())
+    if rc != 0:
+        try:
+            sync.zero_()
+        except Exception:          # noqa: BLE001
+            pass
+    _lib.check(rc, "rwkv7_tmix_gemms")
+
+
 def skinny_linear_partial(x, weight, splits: int, partials, row_halves: bool = False):
     """Split-K partial sums of x @ weight.T into `partials` (fp32, room for [splits, M, N]); returns the view
     [splits_used, M, N].  The consumer (add_ln_mix(delta_partials=...)) does the reduction."""

@@ -208,6 +208,8 @@ class RWKV_x070:
         self.lora_per_problem = True                     # above 256 rows: one library GEMM per LoRA at its own rank, bias in the epilogue
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
+        self.chain_tmix_gemms = True                     # ... and the LoRA up-projections in that SAME launch, on the CUs R/K/V leaves idle
+        self.chain_min_rows = 128                        # (the row-halves regime of that launch)
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
         self.skinny_head = True                          # the head GEMM too (7.2B: -0.05 ms at bsz 200, -0.17 at 32, -0.25 at 1)
@@ -477,7 +479,20 @@ class RWKV_x070:
             main = torch.cuda.current_stream()
             side = self._side if self.overlap_lora else None
             grouped = hw and self.group_tmix_gemms
-            if grouped:
+            chained = (grouped and self.chain_tmix_gemms and ops.TMIX_CHAIN and rows >= self.chain_min_rows and rh["rkv"]
+                       and lw.lora2_t is not None and lw.rkv_t is not None and not gs["rkv"])
+            if chained:
+                # ONE launch for R/K/V AND the whole LoRA chain: down-projections, activations and up-projections run on the CUs
+                # the R/K/V tiles leave idle, beside them (chain_gemm_kernel) -- no second launch for the up-projections
+                rkv = new(3, rows, C)
+                hid = new(4 - p0, rows, lw.lora1.shape[1])
+                up = new(4 - p0, rows, C)
+                main_p = [(mixed[j], lw.rkv_t[j], rkv[j]) for j in range(3)]
+                lora_p = [(mixed[2 + j], lw.lora1[j, :lw.lora_k[j]], j - p0, lw.lbias[j].view(-1), up[j - p0],
+                           ("tanh" if j == 1 else ("sigmoid" if j == 3 else None)), lw.lora_k[j]) for j in range(p0, 4)]
+                ops.tmix_gemms(main_p, lora_p, lw.lora2_t[p0:], hid)
+                side = None
+            elif grouped:
                 # ONE launch for R/K/V and the LoRA down-projections (+ their activations in its reduce), then the
                 # LoRA up-projections, all on this stream: no cross-stream edges (they cost ~19 us per layer)
                 rkv = new(3, rows, C)
@@ -683,6 +698,7 @@ class DecodeGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             ops.reset_tile_counters(model.device)         # a memset node: every replay starts from zeroed tile counters
+            ops.reset_chain_sync(model.device)            # ... and zeroed hand-off words of the time-mix launches
             self.logits = model.forward_seq_batch(self.tokens, state)
         torch.cuda.synchronize()
         for t, s in zip(state, snap):
@@ -729,6 +745,7 @@ class SlotDecodeGraph:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             ops.reset_tile_counters(dev)                  # a memset node: every replay starts from zeroed tile counters
+            ops.reset_chain_sync(dev)
             self.logits = fwd()
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):

@@ -66,13 +66,17 @@ class ArenaRef:
 class HbmStateArena:
     """Preallocated pool of ``capacity`` RWKV-7 request states on one device."""
 
-    def __init__(self, n_layer: int, n_embd: int, capacity: int, device, head_size: int = 64, dtype=torch.float16):
+    def __init__(self, n_layer: int, n_embd: int, capacity: int, device, head_size: int = 64, dtype=torch.float16,
+                 wkv_shape=None, wkv_dtype=None):
+        """wkv_shape / wkv_dtype: per-layer shape and dtype of state[1] when they are not the model's [H, 64, 64] binary16
+        (host-logic tests with a fake backend)."""
         if capacity <= 0:
             raise ValueError("capacity must be positive")
         self.n_layer, self.n_embd, self.capacity = n_layer, n_embd, capacity
         H = n_embd // head_size
+        wkv_shape = tuple(wkv_shape) if wkv_shape is not None else (H, head_size, head_size)
         self.shift = torch.empty((capacity, n_layer, 2, n_embd), dtype=dtype, device=device)            # state[0] rows
-        self.wkv = torch.empty((capacity, n_layer, H, head_size, head_size), dtype=dtype, device=device)  # state[1] rows
+        self.wkv = torch.empty((capacity, n_layer) + wkv_shape, dtype=wkv_dtype or dtype, device=device)  # state[1] rows
         self.elapsed = torch.zeros((capacity,), dtype=torch.int32, device=device)                       # state[2]
         self._free = list(range(capacity - 1, -1, -1))
         self._pins = [0] * capacity
@@ -180,7 +184,9 @@ class TrieNode:
 
 
 class SimpleStateCache:
-    def __init__(self, max_size: int = 100, arena: Optional[HbmStateArena] = None):
+    def __init__(self, max_size: int = 100, arena=None):
+        """arena: an HbmStateArena (thread mode: the states live in this process's HBM pool) or the engine's
+        remote_arena.RemoteArena (process mode: they live in the worker processes' pools, this cache keeps row addresses)."""
         if max_size <= 0:
             raise ValueError("capacity must be positive")
         if arena is not None and arena.capacity < max_size:
@@ -264,17 +270,19 @@ class SimpleStateCache:
             node = node.children.setdefault(tok, TrieNode())
             node.entries += 1
         node.state = True
-        if self.arena is not None and isinstance(state, ArenaRef) and state.arena is self.arena:
+        handle = hasattr(state, "row") and hasattr(state, "release")      # an ArenaRef, or a remote_arena.RemoteStateRef
+        in_arena = self.arena is not None and getattr(self.arena, "accepts_tensors", True)
+        if self.arena is not None and handle and state.arena is self.arena:
             if len(self._lru) >= self.max_size:      # the state already sits in a row (Worker export): take the row over
                 old_key, old_state = self._lru.popitem(last=False)
                 self._drop_path(old_key)
                 self._discard_state(old_state)
             self._lru[tokens] = _ArenaRow(self.arena.adopt(state))
         else:
-            if isinstance(state, ArenaRef):
+            if handle:
                 state = state.tensors()
-            self._lru[tokens] = _ArenaRow(self._put_after_eviction(state)) if self.arena is not None else state
-        if self.arena is None and len(self._lru) > self.max_size:
+            self._lru[tokens] = _ArenaRow(self._put_after_eviction(state)) if in_arena else state
+        if not in_arena and len(self._lru) > self.max_size:
             old_key, old_state = self._lru.popitem(last=False)
             self._drop_path(old_key)
             self._discard_state(old_state)

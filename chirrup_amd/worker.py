@@ -83,7 +83,7 @@ class Worker:
     def __init__(self, worker_id: str, gpu_id: List[int], model_config: ModelLoadConfig, task_queue: queue.Queue,
                  master_event_queue: queue.Queue, worker_event_queue: Optional[queue.Queue], batch_size: int = 32,
                  model=None, tokenizer=None, penalize_argmax=None, state_cache_device=None, run_ahead: bool = True,
-                 state_arena=None):
+                 state_arena=None, state_arena_rows: int = 0, peer_arenas=None):
         self.worker_id, self.gpu_id, self.model_config = worker_id, gpu_id, model_config
         self.task_queue, self.master_event_queue, self.worker_event_queue = task_queue, master_event_queue, worker_event_queue
         self.real_state_size = batch_size
@@ -101,6 +101,10 @@ class Worker:
         # an HbmStateArena on this worker's device: prefix states are exported straight into a free arena row (one copy)
         # and travel as ArenaRef handles; without it they are device clones (or host copies, state_cache_device="cpu")
         self.state_arena = state_arena
+        # process mode: build an arena of this many rows on this worker's own device (after the model has loaded) and publish it
+        # to the other worker processes (remote_arena.PeerArenas): prefix states then never leave HBM
+        self.state_arena_rows, self.peer_arenas = int(state_arena_rows), peer_arenas
+        self._pending_installs = []                   # (event, task id): copies out of ANOTHER worker's arena still in flight
         self.run_ahead = run_ahead
         self.on_fatal = None                          # callable(worker, exception), set by the engine
         self._inflight = None                         # the forward whose sampled ids the host has not handled yet
@@ -159,6 +163,16 @@ class Worker:
         self._ids_host = ([torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
                           if dev.type == "cuda" else None)
         self._launches = 0
+        if self.state_arena is None and self.state_arena_rows > 0:
+            from .state_cache import HbmStateArena
+
+            s0, s1 = self.batch_state[0], self.batch_state[1]
+            self.state_arena = HbmStateArena(s0.shape[0], s0.shape[3], self.state_arena_rows, dev, dtype=s0.dtype,
+                                             wkv_shape=s1.shape[2:], wkv_dtype=s1.dtype)
+            if hasattr(self.task_queue, "arena"):
+                self.task_queue.arena = self.state_arena          # exports into it leave this process as row addresses
+            if self.peer_arenas is not None:
+                self.peer_arenas.publish(self.state_arena)
         # decode-step HIP graphs per batch bucket (captured lazily); slot n-1 is the parking slot
         self._graphs = {}
         self.use_graph = bool(getattr(self.model, "fused", False)) and self.device.type == "cuda"
@@ -173,6 +187,8 @@ class Worker:
             if ev.get("type") == "shutdown":
                 self.shutdown_flag = True
                 return True
+            if ev.get("type") == "arena_free" and self.state_arena is not None:
+                self.state_arena.release(int(ev["row"]))       # the engine's cache dropped the prefix: the row may be reused
 
     @staticmethod
     def _is_task_aborted(td) -> bool:
@@ -299,6 +315,20 @@ class Worker:
         elif hasattr(task.state, "install_into"):   # prefix-cache hit out of an HbmStateArena: row -> slot, one copy, unpin
             task.state.install_into(self.batch_state, slot)
             task.state.release()
+        elif isinstance(task.state, dict) and "__remote_row__" in task.state:
+            # process mode: the address of a row in a worker's arena -- this worker's own (one local copy) or another worker's,
+            # read through its IPC handle (remote_arena.PeerArenas); the engine learns when the copy has COMPLETED
+            wid, row = task.state["__remote_row__"]
+            if self.peer_arenas is None:
+                raise RuntimeError("a remote arena row arrived at a worker without peer arenas")
+            self.peer_arenas.install(wid, int(row), self.batch_state, slot)
+            peer = wid != self.worker_id
+            if peer and s1.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending_installs.append((ev, task.task_id))
+            else:                                    # own row: later writers of the row queue behind this copy on this stream
+                self.task_queue.installed(task.task_id, peer)
         else:                                    # prefix-cache hit: [L,2,1,C], [L,1,H,64,64], [1]
             s0[:, :, [slot], :] = task.state[0].to(s0.device, non_blocking=True)
             s1[:, [slot], :, :] = task.state[1].to(s1.device, non_blocking=True)
@@ -433,6 +463,14 @@ class Worker:
         (2) enqueue this iteration's forward(s), (3) handle sampled ids -- those of the PREVIOUS iteration's
         forward when running ahead, else this one's."""
         t0 = time.perf_counter()
+        if self._pending_installs:                     # copies out of another worker's arena: report those that have completed
+            still = []
+            for ev, task_id in self._pending_installs:
+                if ev.query():
+                    self.task_queue.installed(task_id, True)
+                else:
+                    still.append((ev, task_id))
+            self._pending_installs = still
         done = []
         for slot in range(self.max_batch_size):
             td = self.state_slot[slot]

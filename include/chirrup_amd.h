@@ -284,6 +284,35 @@ int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M
                           int row_halves, void *workspace, void *tile_counters, void *stream);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
                     void *Y, int ldy, int act, int splits, int row_halves, void *workspace, void *tile_counters, void *stream);
+/*
+ * R/K/V and the WHOLE LoRA chain of one RWKV-7 layer (Albatross/rwkv7.py:625-630, :637: four down-projections, tanh / sigmoid,
+ * four up-projections + bias) in ONE launch: the chain runs on the CUs the R/K/V tiles leave idle, beside them, instead of as
+ * a second launch behind them (round 2: 12 us per layer at 7.2B / bsz 200).
+ *   main[i]  (n_main <= 4):  y = x . w^T                                        (as chirrup_gemm_problem; act as there)
+ *   lora[p]  (n_lora <= 4):  hid = act(x . w^T)  [M][n of ld_hid], then  y = hid[:, :k_up] . w_up^T + bias  [M][up_n of up_ldy]
+ * 32 < M <= 256 rows, shared K (% 64), ldx; w of lora[p] row-major [n][K] (row stride ldw, n % 64 == 0); w_up a tile image
+ * (skinny_tile_weight) of [up_n][up_kimg] whose first k_up columns are multiplied (k_up <= n, % 64); act: 0 none, 2 tanh,
+ * 3 sigmoid.  workspace: rwkv7_tmix_gemms_workspace_bytes bytes; sync: rwkv7_tmix_sync_words() ints -- both hipMalloc'ed, sync
+ * ZERO before the first launch (every completed launch leaves it zero; the workgroups hand tiles to each other through it with
+ * write-through stores, one agent-scope atomic per workgroup and ONE agent-scope acquire per consumer: cdna_hip_programming.md
+ * Guideline 16).  Every wait is bounded (spin_limit polls of ~0.25 us, 0 = default ~0.1 s): if one gives up -- another tenant
+ * held most of the chip that long -- the LAST sync word is set non-zero and this launch's LoRA outputs are undefined.
+ * One launch at a time per (workspace, sync).
+ */
+typedef struct {
+    const void *x;      /* [M][ldx] binary16 */
+    const void *w;      /* down-projection [n][K] binary16, row stride ldw */
+    void *hid;          /* [M][ld_hid] binary16: columns [0, n) are written */
+    const void *w_up;   /* tile image of the up-projection [up_n][up_kimg] */
+    const void *bias;   /* [up_n] binary16 or NULL */
+    void *y;            /* [M][up_ldy] binary16 */
+    int n, k_up, act;
+} chirrup_lora_problem;
+int rwkv7_tmix_sync_words(void);
+int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_lora, const chirrup_lora_problem *lora);
+int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
+                     const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, void *workspace, void *sync,
+                     int spin_limit, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight

@@ -233,3 +233,65 @@ def test_hard_exit_of_a_worker_process_releases_its_clients_and_fails_init_fast(
         eng.shutdown()
 
     asyncio.run(main())
+
+
+def test_process_mode_prefix_states_travel_as_arena_row_addresses():
+    """worker_mode="process" with state_arena_rows: every worker process owns an arena (here on the CPU, shared memory standing
+    in for HIP IPC -- the GPU form is tests/test_engine_gpu.py) and ONLY row addresses cross the process boundary.  A prefill
+    exported by one worker is cached in the engine process as (worker, row); hits queued with affinity are installed by the
+    owner, hits queued without affinity are also installed by the OTHER process out of the owner's arena; all streams equal the
+    uncached stream; evicting a prefix hands the row back to its worker exactly once, and only after the last hit on it has
+    reported its copy complete."""
+    from chirrup_amd.remote_arena import RemoteStateRef
+    from chirrup_amd.state_cache import SimpleStateCache
+
+    async def run(affinity):
+        eng = AsyncEngineCore(worker_factory=_process_factory, tokenizer=_Tok(), worker_mode="process", state_arena_rows=4,
+                              prefix_affinity=affinity)
+        cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=2, model_config=cfg, batch_size=4), 120)
+        cache = SimpleStateCache(max_size=2, arena=eng.state_arena)
+        kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[])
+        prompts = [list(range(1 + 3 * i, 25 + 3 * i)) for i in range(3)]
+        for p in prompts[:2]:
+            c = eng.completion("", prefill_tokens=list(p), max_tokens=4, cache_prefill=True, cache_prefill_padding=3, **kw)
+            evs = [ev async for ev in c]
+            hit = [e[1] for e in evs if e[0] == "cache_prefill"]
+            assert len(hit) == 1 and isinstance(hit[0]["state"], RemoteStateRef)          # an address, no tensor
+            assert [e[1] for e in evs if e[0] == "token"] == expected_stream(p, 4)
+            cache.cache(hit[0]["prefilled_tokens"], hit[0]["state"])
+        assert len(cache) == 2 and eng.state_arena.freed == []
+        # hits: many at once, so that with the shared queue both processes pull some of them
+        for rounds in range(3):
+            cs = []
+            for p in prompts[:2] * 3:
+                rest, state, n_hit = cache.check(list(p))
+                assert isinstance(state, RemoteStateRef) and n_hit == len(p) - 3
+                cs.append((p, eng.completion("", prefill_tokens=rest, state=state, max_tokens=5, **kw)))
+            outs = await asyncio.wait_for(asyncio.gather(*[c.get_full_completion() for _, c in cs]), 60)
+            for (p, _), text in zip(cs, outs):
+                assert text == "".join(f"<{t}>" for t in expected_stream(p, 5))
+        inst = dict(eng._router.installs)
+        assert inst["local"] + inst["peer"] == 18
+        # a third prefix evicts the least recently used one: its row goes back to its worker (exactly one free message)
+        c = eng.completion("", prefill_tokens=list(prompts[2]), max_tokens=2, cache_prefill=True, cache_prefill_padding=3, **kw)
+        evs = [ev async for ev in c]
+        hit = [e[1] for e in evs if e[0] == "cache_prefill"][0]
+        cache.cache(hit["prefilled_tokens"], hit["state"])
+        assert len(cache) == 2 and len(eng.state_arena.freed) == 1
+        # ... and both arenas can take new exports for ever: 12 more prefixes through a 2-entry cache over 2 x 4 rows
+        for i in range(12):
+            p = list(range(2 + i, 30 + i))
+            c = eng.completion("", prefill_tokens=list(p), max_tokens=2, cache_prefill=True, cache_prefill_padding=3, **kw)
+            evs = [ev async for ev in c]
+            hit = [e[1] for e in evs if e[0] == "cache_prefill"][0]
+            assert isinstance(hit["state"], RemoteStateRef)                               # never the host-tensor fallback of a full arena
+            cache.cache(hit["prefilled_tokens"], hit["state"])
+        assert len(eng.state_arena.freed) == 13
+        eng.shutdown()
+        return inst
+
+    with_affinity = asyncio.run(run(True))
+    assert with_affinity["peer"] == 0 or with_affinity["local"] > 0      # the owner pulls its own hits first
+    without = asyncio.run(run(False))
+    assert without["peer"] > 0                                            # the other process installed some through the owner's arena

@@ -84,16 +84,18 @@ def _one_graph_step_vs_oracle(zd, z_np, L, B, int8, seed, C=C, V=V, check=None):
     lg = graph.step(toks).cpu().numpy()
     err = {"logits": rel_linf(lg, lg_np), "wkv": rel_linf(st[1].cpu().numpy(), st_np[1]),
            "shift": rel_linf(st[0].cpu().numpy(), st_np[0])}
-    # the binary16 claim behind the relative bars: the WKV state is off by at most ONE unit in the last place of the tensor's
-    # top binade (an element-wise ulp bound cannot hold: the kernel is bit-exact, its INPUTS -- GEMM outputs one ulp apart at
-    # their own magnitude -- move small state elements by several of their own, much smaller, ulps)
+    # the binary16 statement behind the relative bars, in units in the last place of the tensor's TOP binade (an element-wise
+    # ulp bound cannot hold: the kernel is bit-exact, its INPUTS -- GEMM outputs one ulp apart at their own magnitude -- move
+    # small state elements by several of their own, much smaller, ulps): at most 2 such ulps, and no further from the oracle
+    # than a second CPU evaluation of the same arithmetic in another summation order is, plus one (measured at 7.2B / bsz 200:
+    # GPU 1.50, second CPU evaluation 1.75, max|S| = 4.5 so one ulp = 3.9e-3)
     s1_got, s1_want = st[1].cpu().numpy().astype(F32), st_np[1].astype(F32)
     top_ulp = ulp16(np.abs(s1_want).max())
     ulps = float(np.abs(s1_got - s1_want).max() / top_ulp)
     floor_ulps = float(np.abs(st_alt[1].astype(F32) - s1_want).max() / top_ulp)
     print(f"C={C} L={L} B={B} int8={int8}: err {err} floor {floor}; wkv state max|d| = {ulps:.2f} ulp of the top binade "
           f"(max|S| = {np.abs(s1_want).max():.3f}; a second CPU evaluation: {floor_ulps:.2f})")
-    assert ulps <= (1.0 if not int8 else 2.0), ulps
+    assert ulps <= (2.0 if not int8 else 3.0) and ulps <= floor_ulps + 1.0, (ulps, floor_ulps)
     assert st[2].cpu().numpy().tolist() == st_np[2].tolist()
     if check is not None:
         check(model)

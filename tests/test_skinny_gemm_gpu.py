@@ -434,3 +434,73 @@ def test_in_launch_pair_reduction_of_a_grouped_launch():
             got = run()
             assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         assert int(ops._tile_counters(mixed.device).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,C,ranks,p0", [(200, 4096, [128, 128, 128, 512], 0), (200, 4096, [128, 128, 128, 512], 1),
+                                          (130, 2048, [64, 128, 128, 256], 0), (256, 1024, [64, 64, 64, 192], 0), (40, 768, [64, 64, 64, 128], 1)])
+def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0):
+    """rwkv7_tmix_gemms: R/K/V and the whole LoRA chain (down-projections, tanh / sigmoid, up-projections + bias) in ONE launch,
+    the chain on the CUs the R/K/V tiles leave idle, its stages handed from workgroup to workgroup inside the launch.  Against
+    the two launches it replaces (skinny_group + skinny_bmm): R/K/V bit-identical (the same unsplit sums); the hidden planes
+    differ only by the binary32 order of a 4-way K split (<= 1 binary16 ulp before the activation); the up-projections within
+    the GEMM bar of binary64.  hid / outputs are poisoned with NaN before every launch, so a consumer that read a tile before its
+    producer published it shows as NaN; repeated 20 times, with a competing memory stream on another stream in half of the
+    runs (uneven load); every hand-off word is back at zero and the status word clear after each launch."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(M + C + p0)
+    K, dmax = C, (max(ranks) + 63) // 64 * 64
+    mixed = torch.randn(6, M, K, device="cuda").half()
+    rkv_w = [ops.tile_weight((torch.randn(C, K, device="cuda") / K ** 0.5).half()) for _ in range(3)]
+    lora1 = torch.zeros(4, dmax, K, device="cuda", dtype=torch.float16)
+    lora2 = torch.zeros(4, C, dmax, device="cuda", dtype=torch.float16)
+    for j, r in enumerate(ranks):
+        lora1[j, :r] = (torch.randn(r, K, device="cuda") / K ** 0.5).half()
+        lora2[j, :, :r] = (torch.randn(C, r, device="cuda") / r ** 0.5).half()
+    lora2_t = ops.tile_weight_batch(lora2)
+    lbias = torch.randn(4, 1, C, device="cuda").half()
+    acts = [None, "tanh", None, "sigmoid"]
+    nz = 4 - p0
+
+    def old():
+        rkv = torch.empty(3, M, C, device="cuda", dtype=torch.float16)
+        hid = torch.zeros(nz, M, dmax, device="cuda", dtype=torch.float16)
+        probs = [(mixed[j], rkv_w[j], rkv[j], None, None) for j in range(3)]
+        probs += [(mixed[2 + j], lora1[j, :ranks[j]], hid[j - p0, :, :ranks[j]], None, acts[j]) for j in range(p0, 4)]
+        ops.skinny_group(probs, splits=1, row_halves=True)            # unsplit: the sums the chain launch's R/K/V tiles form too
+        up = ops.skinny_bmm(hid, lora2_t[p0:], lbias[p0:], splits=1, k_of=ranks[p0:], row_halves=True)
+        return rkv, hid, up
+
+    want_rkv, want_hid, want_up = old()
+    rkv = torch.empty(3, M, C, device="cuda", dtype=torch.float16)
+    hid = torch.empty(nz, M, dmax, device="cuda", dtype=torch.float16)
+    up = torch.empty(nz, M, C, device="cuda", dtype=torch.float16)
+    main_p = [(mixed[j], rkv_w[j], rkv[j]) for j in range(3)]
+    lora_p = [(mixed[2 + j], lora1[j, :ranks[j]], j - p0, lbias[j].view(-1), up[j - p0], acts[j], ranks[j]) for j in range(p0, 4)]
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, device="cuda", dtype=torch.float16)
+    ref_up = []
+    for j in range(p0, 4):
+        h = (mixed[2 + j].double() @ lora1[j, :ranks[j]].double().t()).half().double()
+        h = torch.tanh(h) if acts[j] == "tanh" else (torch.sigmoid(h) if acts[j] == "sigmoid" else h)
+        ref_up.append(h.half().double() @ lora2[j, :, :ranks[j]].double().t() + lbias[j].double())
+    for it in range(20):
+        rkv.fill_(float("nan")), hid.fill_(float("nan")), up.fill_(float("nan"))
+        if it & 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                noise.add_(1)                                   # a competing kernel while the launch runs
+        ops.tmix_gemms(main_p, lora_p, lora2_t[p0:], hid)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        assert ops.chain_status() == 0
+        assert all(int(t.abs().sum()) == 0 for t in ops._chain_sync.values())
+        assert torch.equal(rkv, want_rkv)
+        for j in range(p0, 4):
+            z, r = j - p0, ranks[j]
+            got_h, want_h = hid[z, :, :r].float(), want_hid[z, :, :r].float()
+            assert not bool(torch.isnan(got_h).any()), (it, j)
+            assert float((got_h - want_h).abs().max()) <= 2e-3 * max(1.0, float(want_h.abs().max())), (it, j)
+            assert not bool(torch.isnan(up[z]).any()), (it, j)
+            assert bool(((up[z].double() - ref_up[z]).abs() <= 4e-3 * ref_up[z].abs().clamp_min(1.0)).all()), (it, j)
+            assert float((up[z].float() - want_up[z].float()).abs().max()) <= 8e-3 * max(1.0, float(want_up[z].abs().max()))
