@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--splits", default=None, help="K-split factors rkv,att_out,ffn_key,ffn_value of the hand-written GEMMs (0 = library's choice), tuning only")
     p.add_argument("--row-halves", default=None, help="1/0 for rkv,att_out,ffn_key,ffn_value: two workgroups per GEMM tile, one per half of the rows; tuning only")
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
+    p.add_argument("--chain-min-rows", type=int, default=None, help="batch rows from which R/K/V and the LoRA chain share one launch, tuning only")
     p.add_argument("--no-chain", action="store_true", help="LoRA up-projections as a launch of their own instead of inside the R/K/V launch, A/B only")
     p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
@@ -202,7 +203,7 @@ def gemm_shape_timings(model, B):
             ops.skinny_bmm(hid, lw.lora2_t if lw.lora2_t is not None else lw.lora2, lw.lbias, splits=1, k_of=ranks, row_halves=model.lora_up_row_halves)
 
     out["lora_up"] = (_replay_time(lora_up, L), n_dn * C * 2 + B * n_dn * 2 + 4 * B * C * 2, "batched launch of the 4 LoRA up-projections, bias in the epilogue")
-    chained = (model.chain_tmix_gemms and ops.TMIX_CHAIN and B >= model.chain_min_rows and rh["rkv"] and lws[0].lora2_t is not None
+    chained = (model.chain_tmix_gemms and ops.TMIX_CHAIN and B >= model.chain_min_rows and (rh["rkv"] or B <= 128) and lws[0].lora2_t is not None
                and not gs["rkv"])
     if chained:
         up = torch.empty((4, B, C), dtype=torch.float16, device=dev)
@@ -212,7 +213,7 @@ def gemm_shape_timings(model, B):
                 main_p = [(mixed[j], lw.rkv_t[j], rkv[j]) for j in range(3)]
                 lora_p = [(mixed[2 + j], lw.lora1[j, :ranks[j]], j, lw.lbias[j].view(-1), up[j],
                            "tanh" if j == 1 else ("sigmoid" if j == 3 else None), ranks[j]) for j in range(4)]
-                ops.tmix_gemms(main_p, lora_p, lw.lora2_t, hid)
+                ops.tmix_gemms(main_p, lora_p, lw.lora2_t, hid, row_halves=rh["rkv"])
 
         both = out["rkv_lora_down"][1] + out["lora_up"][1] - 2 * B * n_dn * 2     # hid is written and read inside the launch
         out["tmix_chain"] = (_replay_time(tmix_chain, L), both,
@@ -566,6 +567,8 @@ def main():
         _ops.PAIR_REDUCE = False
     if a.no_chain:
         model.chain_tmix_gemms = False
+    if a.chain_min_rows is not None:
+        model.chain_min_rows = a.chain_min_rows
     if a.row_halves_min_rows is not None:
         model.row_halves_min_rows = a.row_halves_min_rows
     if a.lora_row_halves is not None:

@@ -668,12 +668,15 @@ struct ChainTable {
     f16 *uY[4];                  // [M][up_ldy]
     int dN[4], dact[4], dfirst[5], uK[4];
     int n_lora, n_chain, dsplits, ld_hid, up_N, up_Kimg, up_ldy;
+    int halves;                  // 2: every tile as two workgroups over the two halves of the rows (M > 32); 1: whole rows
+    int rkv_splits;              // halves == 1 only: K-slices of an R/K/V tile, reduced inside the launch by the last to arrive (EPI_PAIR)
     float *slab;                 // [down tile][half][slice][16 MT][128] binary32
     int *sync;                   // kChainTickets tickets, then kChainDone done counters, then {finished, status}
     int spin_limit;
     unsigned long long *stamps;  // diagnostic (skinny_gemm_clock_probe): 8 x 100-MHz time stamps per workgroup
 };
-constexpr int kChainTickets = 64, kChainDone = 8, kChainWords = kChainTickets + kChainDone + 2, kChainMaxSplits = 4;
+constexpr int kChainTickets = 64, kChainDone = 8, kChainPairs = 512, kChainMaxSplits = 4;
+constexpr int kChainWords = kChainTickets + kChainDone + 2 + kChainPairs;     // ... then the R/K/V tiles' tickets (rkv_splits > 1)
 
 // one K-range of one 128-column tile: prologue, main loop; leaves the sums in `acc` and EVERY wave behind a barrier (the
 // ring is free again).  Loader waves come back too (ring_gemm_kernel's leave at this point).  D: ring slots.
@@ -778,28 +781,50 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
     const int m0 = MT * 16;                                               // rows of the first half
 
     if (L >= ct.n_chain) {
-        // ---- an R/K/V tile half (ring_gemm_kernel's EPI_F16 path; the tile order is XCD-aware as tile_of_block's)
+        // ---- an R/K/V tile: one half of its rows (halves == 2; ring_gemm_kernel's EPI_F16 path), or one of its K-slices (rkv_splits
+        //      > 1: EPI_PAIR, the last slice to arrive reduces), or all of it; the tile order is XCD-aware as tile_of_block's
         const int Lr = L - ct.n_chain, total = (int)gridDim.x - ct.n_chain;
         int v = (total & 7) ? Lr : (Lr & 7) * (total >> 3) + (Lr >> 3);
-        const int half = v & 1;
-        v >>= 1;
+        int half = 0, kslice = 0;
+        if (ct.halves == 2) {
+            half = v & 1;
+            v >>= 1;
+        } else if (ct.rkv_splits > 1) {
+            kslice = v % ct.rkv_splits;
+            v /= ct.rkv_splits;
+        }
         if (v >= gt.first[gt.used]) return;
         int b = 0;
         while (b + 1 < gt.used && v >= gt.first[b + 1]) b++;
         Tile t;
-        t.ngroup = v - gt.first[b], t.kslice = 0, t.batch = b, t.pair_id = 0;
+        t.ngroup = v - gt.first[b], t.kslice = kslice, t.batch = b, t.pair_id = v;
         t.rows0 = half ? m0 : 0;
-        t.M = half ? M - m0 : m0;
+        t.M = ct.halves == 2 ? (half ? M - m0 : m0) : M;
         t.X = gt.X[b] + (int64_t)t.rows0 * ldx, t.W = gt.W[b], t.Y = gt.Y[b] + (int64_t)t.rows0 * gt.ldy[b];
-        t.bias = gt.bias[b], t.part = nullptr, t.Np = gt.N[b], t.ldy = gt.ldy[b], t.act = gt.act[b], t.w_tiled = gt.tiled[b] != 0;
-        const int n_base = t.ngroup * 128;
+        t.bias = gt.bias[b], t.part = gt.part[b], t.Np = gt.N[b], t.ldy = gt.ldy[b], t.act = gt.act[b], t.w_tiled = gt.tiled[b] != 0;
+        const int n_base = t.ngroup * 128, k_slice = K / ct.rkv_splits;
         if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8] = __builtin_amdgcn_s_memrealtime();
-        chain_mainloop<MT, ring_depth<MT, false>()>(t, ldx, ldw, K, 0, K / kKB, n_base, smem, acc);
+        chain_mainloop<MT, ring_depth<MT, false>()>(t, ldx, ldw, K, kslice * k_slice, k_slice / kKB, n_base, smem, acc);
         if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (!computes) return;
         if (n_base + wave * 32 < t.Np) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
         __syncthreads();                               // (the four compute waves; finished waves do not count)
-        store_staged<EPI_F16, 256>(stg, t.M, n_base, t, 0, M);
+        if (ct.rkv_splits > 1) {                       // ring_gemm_kernel's EPI_PAIR epilogue (same hand-off, same bits as a reduce launch)
+            int *const pair = ct.sync + kChainTickets + kChainDone + 2 + t.pair_id;
+            store_staged_sc1<256>(stg, t.M, n_base, t, t.kslice);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int drawn = __hip_atomic_fetch_add(pair, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (drawn == ct.rkv_splits - 1) __hip_atomic_store(pair, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = drawn == ct.rkv_splits - 1;
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (*flag) combine_store<256>(stg, t.M, n_base, t, t.kslice, ct.rkv_splits);
+        } else {
+            store_staged<EPI_F16, 256>(stg, t.M, n_base, t, 0, M);
+        }
         if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8 + 7] = __builtin_amdgcn_s_memrealtime();
         return;
     }
@@ -815,7 +840,8 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
     stamp(0);
     // this workgroup's share of the up-projection tile halves: half-major, then column tile, problem fastest -- a contiguous share
     // lies in one half (two at most) and mixes the problems' lengths
-    const int ctiles = (ct.up_N + 127) / 128, U = ct.n_lora * ctiles * 2, per_half = ct.n_lora * ctiles;
+    const int H = ct.halves;
+    const int ctiles = (ct.up_N + 127) / 128, U = ct.n_lora * ctiles * H, per_half = ct.n_lora * ctiles;
     const int lo = (int)((int64_t)L * U / ct.n_chain), hi = (int)((int64_t)(L + 1) * U / ct.n_chain);
     // Warm THIS XCD's L2 with the up-projection weights this workgroup will stream later (a few hundred KB, contiguous runs of
     // a tile image): issued by the compute waves now, while they wait for the first stage anyway; nobody waits for the data.
@@ -829,15 +855,15 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
         }
     }
     bool ok = true;
-    if (L < n_dtiles * 2 * ct.dsplits) {
-        // 1. one K-slice of one down-projection tile half
-        const int slice = L % ct.dsplits, th = L / ct.dsplits, half = th & 1, dtile = th >> 1;
+    if (L < n_dtiles * H * ct.dsplits) {
+        // 1. one K-slice of one down-projection tile (half)
+        const int slice = L % ct.dsplits, th = L / ct.dsplits, half = th % H, dtile = th / H;
         int p = 0;
         while (p + 1 < ct.n_lora && dtile >= ct.dfirst[p + 1]) p++;
         Tile t;
-        t.ngroup = dtile - ct.dfirst[p], t.kslice = slice, t.batch = p, t.pair_id = dtile * 2 + half;
+        t.ngroup = dtile - ct.dfirst[p], t.kslice = slice, t.batch = p, t.pair_id = dtile * H + half;
         t.rows0 = half ? m0 : 0;
-        t.M = half ? M - m0 : m0;
+        t.M = H == 2 ? (half ? M - m0 : m0) : M;
         t.X = ct.dX[p] + (int64_t)t.rows0 * ldx, t.W = ct.dW[p], t.Y = ct.hid[p] + (int64_t)t.rows0 * ct.ld_hid;
         t.bias = nullptr, t.part = nullptr, t.Np = ct.dN[p], t.ldy = ct.ld_hid, t.act = ct.dact[p], t.w_tiled = false;
         const int n_base = t.ngroup * 128, k_slice = K / ct.dsplits;
@@ -915,7 +941,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
             const int half = it / per_half, r = it % per_half, p = r % ct.n_lora, ctile = r / ct.n_lora;
             t.ngroup = ctile, t.kslice = 0, t.batch = p, t.pair_id = 0;
             t.rows0 = half ? m0 : 0;
-            t.M = half ? M - m0 : m0;
+            t.M = H == 2 ? (half ? M - m0 : m0) : M;
             t.X = ct.hid[p] + (int64_t)t.rows0 * ct.ld_hid, t.W = ct.uW[p], t.Y = ct.uY[p] + (int64_t)t.rows0 * ct.up_ldy;
             t.bias = ct.ubias[p], t.part = nullptr, t.Np = ct.up_N, t.ldy = ct.up_ldy, t.act = 0, t.w_tiled = true;
             nkb = ct.uK[p] / kKB, n_base = ctile * 128;
@@ -1390,8 +1416,33 @@ __global__ __launch_bounds__(256) void tile_weight_u8_kernel(const int N, const 
     *reinterpret_cast<u32x4 *>(Wt + c * 16) = *reinterpret_cast<const u32x4 *>(W + ((int64_t)ng * kTileRows + nr) * ldw + kb * kKB + lc * 16);
 }
 
+// tile images -> W [N][K] row-major (the inverse of tile_weight_kernel; same chunk walk, source and destination swapped)
+__global__ __launch_bounds__(256) void untile_weight_kernel(const int N, const int K, const f16 *__restrict__ Wt, f16 *__restrict__ W,
+                                                            const int64_t ldw) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = (int64_t)N * K / 8;
+    if (c >= total) return;
+    const int g = (int)(c & 1023);
+    const int64_t tile = c >> 10;
+    const int kb = (int)(tile % (K / kKB)), ng = (int)(tile / (K / kKB));
+    const int nr = g >> 3, lc = (g & 7) ^ ((nr >> 1) & 7);
+    *reinterpret_cast<f16x8 *>(W + ((int64_t)ng * kTileRows + nr) * ldw + kb * kKB + lc * 8) = *reinterpret_cast<const f16x8 *>(Wt + c * 8);
+}
+
 inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 }  // namespace
+
+// Tile images back to a row-major matrix W [N][K] (row stride ldw): for a model that keeps ONLY the tile images of its big
+// matrices (chirrup_amd.rwkv7: keep_row_major=False) and needs a row-major operand for a library GEMM (prefill chunks > 256 rows).
+extern "C" int skinny_untile_weight(int N, int K, const void *Wt, void *W, int64_t ldw, void *stream) {
+    if (N <= 0 || K <= 0 || (N % kTileRows) || (K % kKB) || ldw < K || (ldw & 7)) return CHIRRUP_E_SHAPE;
+    if (!W || !Wt) return CHIRRUP_E_NULL;
+    if (mis16(W) || mis16(Wt)) return CHIRRUP_E_ALIGN;
+    const int64_t total = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(untile_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, K, static_cast<const f16 *>(Wt), static_cast<f16 *>(W), ldw);
+    return (int)hipGetLastError();
+}
 
 // The same for the uint8 (mm8) weights wT [M_out][N_in] of mm8t_seq (w_tiled = 1 there): 8-KiB tile images.
 extern "C" int skinny_tile_weight_u8(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream) {
@@ -1646,13 +1697,14 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
 // R/K/V + the whole LoRA chain of one RWKV-7 layer in ONE launch (chain_gemm_kernel; rwkv7.py:625-630, :637).
 //   main[i]  (i < n_main <= 4): y_i = x_i . w_i^T   (w tile-image, or row-major with row stride ldw)          [M][n_i]
 //   lora[p]  (p < n_lora <= 4): hid_p = act_p(x_p . wd_p^T)  [M][n_p of ld_hid],  y_p = hid_p[:, :k_up_p] . wu_p^T + bias_p  [M][up_n]
-// All x share M (33..256 rows), K and ldx; wd_p row-major [n_p][K] with row stride ldw (n_p % 64 == 0, rows past n_p of a
+// All x share M (1..256 rows; whole-row tiles need M <= 128), K and ldx; wd_p row-major [n_p][K] with row stride ldw (n_p % 64 == 0, rows past n_p of a
 // 128-row tile read as zeros); wu_p tile images of [up_n][up_kimg] (k_up_p <= up_kimg, both % 64 == 0; up_n % 128 == 0).
 // workspace: rwkv7_tmix_gemms_workspace_bytes(...) bytes of hipMalloc'ed memory; sync: rwkv7_tmix_sync_words() ints, ZERO before the
 // first use, zero again after every completed launch (a launch that did not complete: zero them yourself); used by one
-// launch at a time.  sync[rwkv7_tmix_sync_words() - 1] is a STATUS word: non-zero after a launch whose bounded waits gave up
+// launch at a time.  sync[rwkv7_tmix_status_word()] is a STATUS word: non-zero after a launch whose bounded waits gave up
 // (another tenant holding most of the chip for > spin budget): that launch's LoRA outputs are then undefined.
 extern "C" int rwkv7_tmix_sync_words(void) { return kChainWords; }
+extern "C" int rwkv7_tmix_status_word(void) { return kChainTickets + kChainDone + 1; }
 
 namespace {
 int chain_dsplits(int K) {
@@ -1663,19 +1715,43 @@ int chain_dsplits(int K) {
 }
 }  // namespace
 
-extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_lora, const chirrup_lora_problem *lora) {
-    if (M <= 0 || K <= 0 || (K % kKB) || n_lora <= 0 || n_lora > 4 || !lora) return 0;
-    int tiles = 0;
+namespace {
+// how a time-mix launch is cut: two row halves per tile from 128 rows (the R/K/V tiles then run unsplit), whole rows below;
+// at <= 32 rows the R/K/V tiles are split 2..4 ways over K and reduced inside the launch (as ring_gemm_kernel's EPI_PAIR)
+void chain_plan(int M, int K, int main_tiles, int row_halves, int &halves, int &rkv_splits) {
+    halves = (row_halves && M > 32) ? 2 : 1;
+    rkv_splits = 1;
+    if (halves == 1 && M <= 64) {                      // (64: two slices of a 96-tile layer, one 32-KB partial per other slice)
+        int s = (192 + main_tiles / 2) / main_tiles;
+        const int max_s = K / 256 > 0 ? K / 256 : 1;
+        s = s > max_s ? max_s : s;
+        s = s > kPairMaxSlices ? kPairMaxSlices : (s < 1 ? 1 : s);
+        while (s > 1 && ((K / kKB) % s || (s - 1) * M > 96)) s--;
+        rkv_splits = s;
+    }
+}
+}  // namespace
+
+extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
+                                                    const chirrup_lora_problem *lora, int row_halves) {
+    if (M <= 0 || K <= 0 || (K % kKB) || n_lora <= 0 || n_lora > 4 || !lora || n_main <= 0 || n_main > 4 || !main_p) return 0;
+    int tiles = 0, main_tiles = 0;
     for (int p = 0; p < n_lora; p++) tiles += (lora[p].n + kTileRows - 1) / kTileRows;
-    const int MT = tiles_of(M, true);
-    return (int64_t)tiles * 2 * chain_dsplits(K) * (MT * 16) * kTileRows * (int64_t)sizeof(float);
+    for (int i = 0; i < n_main; i++) main_tiles += (main_p[i].n + kTileRows - 1) / kTileRows;
+    int halves, rs;
+    chain_plan(M, K, main_tiles, row_halves, halves, rs);
+    const int MT = tiles_of(M, halves == 2);
+    int64_t b = (int64_t)tiles * halves * chain_dsplits(K) * (MT * 16) * kTileRows * (int64_t)sizeof(float);
+    if (rs > 1)
+        for (int i = 0; i < n_main; i++) b += ((int64_t)rs * M * main_p[i].n * (int64_t)sizeof(float) + 255) / 256 * 256;
+    return b + 256;
 }
 
 extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
-                                const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, void *workspace,
-                                void *sync, int spin_limit, void *stream) {
+                                const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
+                                void *workspace, void *sync, int spin_limit, void *stream) {
     if (n_main <= 0 || n_main > 4 || n_lora <= 0 || n_lora > 4 || !main_p || !lora) return CHIRRUP_E_SHAPE;
-    if (M <= 32 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7)) return CHIRRUP_E_SHAPE;
+    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7)) return CHIRRUP_E_SHAPE;
     if (up_n <= 0 || (up_n % kTileRows) || up_kimg <= 0 || (up_kimg % kKB) || up_ldy < up_n || (up_ldy & 3) || ld_hid < up_kimg || (ld_hid & 7))
         return CHIRRUP_E_SHAPE;
     if (!workspace || !sync) return CHIRRUP_E_NULL;
@@ -1694,6 +1770,7 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
     }
     ChainTable ct{};
     ct.n_lora = n_lora, ct.dsplits = chain_dsplits(K), ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
+    chain_plan(M, K, gt.first[n_main], row_halves, ct.halves, ct.rkv_splits);
     for (int p = 0; p < n_lora; p++) {
         const chirrup_lora_problem &q = lora[p];
         if (q.n <= 0 || (q.n % kKB) || q.n > ld_hid || q.k_up <= 0 || (q.k_up % kKB) || q.k_up > q.n || q.k_up > up_kimg || q.act < 0 || q.act > 3)
@@ -1707,16 +1784,25 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
         ct.dfirst[p + 1] = ct.dfirst[p] + (q.n + kTileRows - 1) / kTileRows;
     }
     const int n_dtiles = ct.dfirst[n_lora];
-    if (n_dtiles * 2 > kChainTickets) return CHIRRUP_E_UNSUPPORTED;
-    const int main_wgs = (gt.first[n_main] * 2 + 15) / 16 * 16;     // two halves per tile; whole runs of the XCD-aware tile order
-    ct.n_chain = (n_dtiles * 2 * ct.dsplits + 7) / 8 * 8;           // the down-projection slices ...
+    const int MT = tiles_of(M, ct.halves == 2);
+    if (n_dtiles * ct.halves > kChainTickets || gt.first[n_main] > kChainPairs) return CHIRRUP_E_UNSUPPORTED;
+    // workspace: the down-projection slabs, then (split R/K/V) one run of partial planes per R/K/V problem
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    ct.slab = reinterpret_cast<float *>(ws);
+    ws += ((int64_t)n_dtiles * ct.halves * ct.dsplits * (MT * 16) * kTileRows * (int64_t)sizeof(float) + 255) / 256 * 256;
+    if (ct.rkv_splits > 1)
+        for (int i = 0; i < n_main; i++) {
+            gt.part[i] = reinterpret_cast<float *>(ws);
+            ws += ((int64_t)ct.rkv_splits * M * gt.N[i] * (int64_t)sizeof(float) + 255) / 256 * 256;
+        }
+    ct.sync = static_cast<int *>(sync);
+    const int main_wgs = (gt.first[n_main] * ct.halves * ct.rkv_splits + 15) / 16 * 16;   // whole runs of the XCD-aware tile order
+    ct.n_chain = (n_dtiles * ct.halves * ct.dsplits + 7) / 8 * 8;   // the down-projection slices ...
     const int spare = (256 - main_wgs) / 8 * 8;                      // ... and every CU the R/K/V tiles leave idle, for the up-projections
     if (spare > ct.n_chain) ct.n_chain = spare < 96 ? spare : 96;
-    ct.slab = static_cast<float *>(workspace), ct.sync = static_cast<int *>(sync);
     ct.spin_limit = spin_limit > 0 ? spin_limit : 400000;          // x ~0.25 us of s_sleep: ~0.1 s
     const dim3 grid(ct.n_chain + main_wgs);
     ct.stamps = (g_clock_probe && g_clock_pairs >= (int)grid.x * 4) ? g_clock_probe : nullptr;
-    const int MT = tiles_of(M, true);
     const size_t lds = lds_bytes(128, MT, false);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define CHAIN_GO(MTV)                                                                                                          \
@@ -1732,13 +1818,15 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, K, ldx, ldw, gt, ct);                                            \
     } while (0)
     switch (MT) {
+        case 1: CHAIN_GO(1); break;
         case 2: CHAIN_GO(2); break;
         case 3: CHAIN_GO(3); break;
         case 4: CHAIN_GO(4); break;
         case 5: CHAIN_GO(5); break;
         case 6: CHAIN_GO(6); break;
         case 7: CHAIN_GO(7); break;
-        default: CHAIN_GO(8); break;
+        case 8: CHAIN_GO(8); break;
+        default: return CHIRRUP_E_UNSUPPORTED;         // whole rows above 128: not used (row halves from 128 rows on)
     }
 #undef CHAIN_GO
     return (int)hipGetLastError();

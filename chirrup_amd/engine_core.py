@@ -64,7 +64,7 @@ class AsyncEngineCore:
         arguments (e.g. run_ahead).  state_arena_rows (process mode): rows of the HBM prefix-state arena EVERY worker process
         builds on its GPU; ``self.state_arena`` is then the engine-side view to hand to ``SimpleStateCache(arena=...)`` -- prefix
         states never leave HBM (chirrup_amd/remote_arena.py).  prefix_affinity=False queues hits on the shared queue instead of
-        the owning worker's (tests: every hit may then be installed through another process's IPC handle).  gpu_ids: device of
+        the owning worker's, "avoid" on ANOTHER worker's (tests: every hit is then installed through the owner's IPC handle).  gpu_ids: device of
         worker k (default k)."""
         if worker_mode not in ("thread", "process", "auto"):
             raise ValueError("worker_mode must be 'thread', 'process' or 'auto'")

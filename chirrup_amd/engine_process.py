@@ -231,6 +231,9 @@ class ProcessTaskQueue:
         if isinstance(task.state, RemoteStateRef):
             self._router.pin(task.task_id, task.state)   # released on "__installed__" (or when the task ends)
             q_ = self._affinity.get(task.state.worker_id) if self.prefix_affinity else None
+            if self.prefix_affinity == "avoid":          # (tests) queue the hit for a worker that does NOT own the row: every
+                others = [w for w in sorted(self._affinity) if w != task.state.worker_id]   # install is a cross-process copy
+                q_ = self._affinity[others[0]] if others else q_
             if q_ is not None:                           # the worker whose arena holds the row pulls it first
                 q_.put(wire)
                 return

@@ -62,13 +62,15 @@ SIGNATURES = {
     "skinny_gemm_f16_group": (_i, [_i, _vp, _i, _i, _i, _i64, _i, _i, _vp, _vp, _vp]),
     "skinny_gemm_pair_counters": (_i, []),
     "rwkv7_tmix_sync_words": (_i, []),
-    "rwkv7_tmix_gemms_workspace_bytes": (_i64, [_i, _i, _i, _vp]),
-    "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "rwkv7_tmix_status_word": (_i, []),
+    "rwkv7_tmix_gemms_workspace_bytes": (_i64, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "skinny_gemm_clock_probe": (_i, [_vp, _i]),
     "chirrup_clock_probe": (_i, [_i, _vp, _vp]),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_tile_weight": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
+    "skinny_untile_weight": (_i, [_i, _i, _vp, _vp, _i64, _vp]),
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

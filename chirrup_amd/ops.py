@@ -436,6 +436,18 @@ def tile_weight(weight: torch.Tensor) -> TiledWeight:
     return TiledWeight(out, N, K)
 
 
+def untile_weight(tw: "TiledWeight", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The row-major [N, K] matrix of a TiledWeight (into `out` [N, K] with unit inner stride when given)."""
+    N, K = tw.shape
+    if out is None:
+        out = torch.empty((N, K), dtype=torch.float16, device=tw.data.device)
+    if tuple(out.shape) != (N, K) or out.dtype != torch.float16 or out.stride(1) != 1 or not out.is_cuda:
+        raise _lib.ChirrupAmdError("untile_weight: out must be a GPU fp16 [N, K] matrix with unit inner stride")
+    rc = _lib.load().skinny_untile_weight(N, K, tw.data.data_ptr(), out.data_ptr(), out.stride(0), _stream())
+    _lib.check(rc, "skinny_untile_weight")
+    return out
+
+
 def _weight_args(weight, K: int, name: str = "weight"):
     """(N, data_ptr, row stride, w_tiled) of a plain [N, K] matrix or a TiledWeight."""
     if isinstance(weight, TiledWeight):
@@ -613,11 +625,11 @@ def reset_chain_sync(device=None) -> None:
 
 def chain_status() -> int:
     """Non-zero when a bounded wait of any time-mix launch of this process gave up (its LoRA outputs were undefined)."""
-    n = _lib.load().rwkv7_tmix_sync_words()
-    return int(sum(int(t[n - 1]) for t in _chain_sync.values()))
+    i = _lib.load().rwkv7_tmix_status_word()
+    return int(sum(int(t[i]) for t in _chain_sync.values()))
 
 
-def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, spin_limit: int = 0) -> None:
+def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, row_halves: bool = True, spin_limit: int = 0) -> None:
     """R/K/V and the whole LoRA chain of a layer in ONE launch (include/chirrup_amd.h: rwkv7_tmix_gemms).
     main: list of (x [M,K], weight [N,K] or TiledWeight, out [M,N]);
     lora: list of (x [M,K], w_down [n,K] row-major, plane index z into hid / up_weight, bias [C] or None, out [M,C], act, k_up);
@@ -656,11 +668,12 @@ def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, spi
     up_ldy = lora[0][4].stride(0)
     if any(p[4].stride(0) != up_ldy for p in lora):
         raise _lib.ChirrupAmdError("tmix_gemms: the up-projection outputs must share their row stride")
-    nbytes = L.rwkv7_tmix_gemms_workspace_bytes(M, K, len(lora), ctypes.addressof(larr))
+    nbytes = L.rwkv7_tmix_gemms_workspace_bytes(M, K, len(main), ctypes.addressof(marr), len(lora), ctypes.addressof(larr), int(row_halves))
     ws, sync = _chain_state(x0.device, nbytes + 256)
     base = (ws.data_ptr() + 255) // 256 * 256
     rc = L.rwkv7_tmix_gemms(M, K, x0.stride(0), ldw if ldw is not None else K, len(main), ctypes.addressof(marr), len(lora),
-                            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, base, sync.data_ptr(), spin_limit, _stream())
+                            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, int(row_halves), base, sync.data_ptr(), spin_limit,
+                            _stream())
     if rc != 0:
         try:
             sync.zero_()

@@ -138,7 +138,10 @@ class PeerArenas:
         self._peers: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
 
     def publish(self, arena) -> None:
-        self.local = arena                                    # (a host arena -- CPU rehearsals -- travels as shared memory)
+        self.local = arena
+        if arena.shift.device.type == "cpu":                  # CPU rehearsals: a host arena travels as shared memory.  Move it
+            for t in (arena.shift, arena.wkv, arena.elapsed):  # there NOW, on this thread: left to the queue's feeder thread the move
+                t.share_memory_()                              # could race with this worker's first export into a row
         for wid, q in self._outboxes.items():
             if wid != self.worker_id:
                 q.put((self.worker_id, arena.shift, arena.wkv, arena.elapsed))     # IPC handles, not bytes

@@ -167,15 +167,48 @@ class _Layer:
         self.f_K = self.f_V = None
 
 
+class _LazyWeights(dict):
+    """``.z`` of a tile-image-only model: the keys whose row-major tensors were freed are rebuilt from their tile images on
+    every access (a new tensor each time -- for inspection and export, not for the hot path)."""
+
+    def __init__(self, base, lazy):
+        self._sizes = {k: base[k].numel() * base[k].element_size() for k in lazy if dict.__contains__(base, k)}
+        super().__init__((k, v) for k, v in base.items() if k not in lazy)
+        self._lazy = lazy
+
+    def nbytes_of(self, key) -> int:
+        return self._sizes[key]
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            return self._lazy[key]()
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get_resident(self, key):
+        return dict.get(self, key)
+
+    def keys(self):
+        return list(dict.keys(self)) + list(self._lazy.keys())
+
+
 class RWKV_x070:
     """See module docstring.  ``wkv_impl`` is a test hook (signature of ops.forward_seq); the
     default is the HIP kernel and nothing else is ever selected automatically."""
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
                  fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16,
-                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 0):
+                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 0, keep_row_major: bool = True):
+        """keep_row_major=False: the six big matrices of every layer (and the head) live ONLY as tile images -- the row-major
+        originals are freed after tiling (-12*C^2*2 B per layer: 12.9 GB at 7.2B, 24.6 GB at 13.3B, HBM that config 5 wants for
+        cached states).  Forwards of more than 256 token rows (library GEMMs) then rebuild a layer's row-major operands into one
+        reused scratch set first (skinny_untile_weight: +0.16 ms per layer at ~5 TB/s of copies, ~11 % of a 2500-row chunk);
+        the reference's keys stay readable in ``.z`` (rebuilt on access)."""
         self.args = args
         self.tiled_weights = bool(tiled_weights)     # second, tile-image copies of the ring GEMM's matrices (_Layer.tile_for_ring)
+        self.keep_row_major = bool(keep_row_major) or not tiled_weights
         args.head_size = HEAD_SIZE
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
@@ -209,7 +242,8 @@ class RWKV_x070:
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.chain_tmix_gemms = True                     # ... and the LoRA up-projections in that SAME launch, on the CUs R/K/V leaves idle
-        self.chain_min_rows = 128                        # (the row-halves regime of that launch)
+        self.chain_min_rows = 33                         # A/B on one box (gpurun_out/r3i): 13.3B bsz 64 8.36 -> 8.07..8.23 ms, 7.2B bsz 128 5.67 -> 5.61..5.68, bsz 200 7.17 -> 6.93;
+                                                         # at <= 32 rows the chain (fixed hand-off latencies, ~17 us) outlasts the R/K/V tiles (~12 us): 1.5B bsz 32 1.80 -> 1.87 ms
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
         self.skinny_head = True                          # the head GEMM too (7.2B: -0.05 ms at bsz 200, -0.17 at 32, -0.25 at 1)
@@ -242,7 +276,55 @@ class RWKV_x070:
                 lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = lw.lora2_t = None
                 if self.tiled_weights and self.n_embd >= self.skinny_min_embd:
                     lw.tile_for_ring()
+            if not self.keep_row_major:
+                self._drop_row_major()
             torch.cuda.empty_cache()
+
+    # ------------------------------------------------------------------ tile-image-only weights (keep_row_major=False)
+    def _drop_row_major(self):
+        """Free the row-major copies of every matrix that has a tile image; ``.z`` rebuilds them on access."""
+        C = self.n_embd
+        if self.ffn_dtype != torch.float16 or self.sparse_bsz1:
+            raise ops._lib.ChirrupAmdError("keep_row_major=False needs the fp16 model without the bsz-1 sparse path")
+        if any(lw.rkv_t is None or lw.O_t is None or lw.f_K_t is None or lw.f_V_t is None for lw in self._layers):
+            raise ops._lib.ChirrupAmdError("keep_row_major=False needs tile images of every big matrix (n_embd % 128 == 0)")
+        hwt = self.z["head.weight"]
+        if hwt.shape[0] % 128 == 0:
+            self._head_t = ops.tile_weight(hwt)
+        lazy = {}
+        for i, lw in enumerate(self._layers):
+            a, f = f"blocks.{i}.att.", f"blocks.{i}.ffn."
+            for j, n in enumerate(("receptance", "key", "value")):
+                lazy[a + n + ".weight"] = (lambda lw=lw, j=j: ops.untile_weight(lw.rkv_t[j]))
+            lazy[a + "output.weight"] = (lambda lw=lw: ops.untile_weight(lw.O_t))
+            lazy[f + "key.weight"] = (lambda lw=lw: ops.untile_weight(lw.f_K_t))
+            lazy[f + "value.weight"] = (lambda lw=lw: ops.untile_weight(lw.f_V_t).t())      # the reference's [4C, C] view
+            lw.rkv = lw.R = lw.K = lw.V = lw.O = lw.f_K = lw.f_V = None
+        if self._head_t is not None and isinstance(self._head_t, ops.TiledWeight):
+            lazy["head.weight"] = (lambda: ops.untile_weight(self._head_t))
+        self.z = _LazyWeights(self.z, lazy)
+        self._scratch = None
+
+    def _row_major(self, lw):
+        """(rkv [3,C,C], O [C,C], f_K [4C,C], f_V view [4C,C]) of a layer for the library GEMMs: the resident tensors, or --
+        tile-image-only model -- rebuilt into ONE scratch set that every layer reuses (stream order keeps that safe)."""
+        if lw.rkv is not None:
+            return lw.rkv, lw.O, lw.f_K, lw.f_V
+        C, dev = self.n_embd, self.device
+        if self._scratch is None:
+            new = lambda *sh: torch.empty(sh, dtype=DTYPE, device=dev)
+            self._scratch = (new(3, C, C), new(C, C), new(4 * C, C), new(C, 4 * C))
+        rkv, O, f_K, f_Vt = self._scratch
+        for j in range(3):
+            ops.untile_weight(lw.rkv_t[j], rkv[j])
+        ops.untile_weight(lw.O_t, O)
+        ops.untile_weight(lw.f_K_t, f_K)
+        ops.untile_weight(lw.f_V_t, f_Vt)
+        return rkv, O, f_K, f_Vt.t()
+
+    def _head_row_major(self):
+        hw = self.z.get_resident("head.weight") if isinstance(self.z, _LazyWeights) else self.z["head.weight"]
+        return hw if hw is not None else self.z["head.weight"]
 
     # ------------------------------------------------------------------ reference surface
     def generate_zero_state(self, bsz: int):
@@ -262,6 +344,9 @@ class RWKV_x070:
         def nbytes(keys):
             tot = 0
             for k in keys:
+                if isinstance(z, _LazyWeights) and k in z._lazy:
+                    tot += z.nbytes_of(k)                    # lives as a tile image of the same size
+                    continue
                 t = z[k] if k in z else z[k + ".mm8"]
                 tot += sum(x.numel() * x.element_size() for x in (t if isinstance(t, tuple) else (t,)))
             return tot
@@ -465,6 +550,8 @@ class RWKV_x070:
             for j in (0, 1):
                 if not s0[i][j].is_contiguous():
                     raise ops._lib.ChirrupAmdError("state[0][layer][j] view must be contiguous (slice the batch dim only)")
+            # library-GEMM operands (more than 256 rows): resident, or rebuilt from the tile images (keep_row_major=False)
+            w_rkv, w_O, w_fK, w_fV = (lw.rkv, lw.O, lw.f_K, lw.f_V) if (hw or lw.rkv is not None) else self._row_major(lw)
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
             upd = delta is not None or dparts is not None
@@ -479,7 +566,7 @@ class RWKV_x070:
             main = torch.cuda.current_stream()
             side = self._side if self.overlap_lora else None
             grouped = hw and self.group_tmix_gemms
-            chained = (grouped and self.chain_tmix_gemms and ops.TMIX_CHAIN and rows >= self.chain_min_rows and rh["rkv"]
+            chained = (grouped and self.chain_tmix_gemms and ops.TMIX_CHAIN and rows >= self.chain_min_rows and (rh["rkv"] or rows <= 128)
                        and lw.lora2_t is not None and lw.rkv_t is not None and not gs["rkv"])
             if chained:
                 # ONE launch for R/K/V AND the whole LoRA chain: down-projections, activations and up-projections run on the CUs
@@ -490,7 +577,7 @@ class RWKV_x070:
                 main_p = [(mixed[j], lw.rkv_t[j], rkv[j]) for j in range(3)]
                 lora_p = [(mixed[2 + j], lw.lora1[j, :lw.lora_k[j]], j - p0, lw.lbias[j].view(-1), up[j - p0],
                            ("tanh" if j == 1 else ("sigmoid" if j == 3 else None)), lw.lora_k[j]) for j in range(p0, 4)]
-                ops.tmix_gemms(main_p, lora_p, lw.lora2_t[p0:], hid)
+                ops.tmix_gemms(main_p, lora_p, lw.lora2_t[p0:], hid, row_halves=rh["rkv"])
                 side = None
             elif grouped:
                 # ONE launch for R/K/V and the LoRA down-projections (+ their activations in its reduce), then the
@@ -540,9 +627,9 @@ class RWKV_x070:
             elif rows >= self.split_rows_min:
                 rkv = new(3, rows, C)                       # three GEMMs at 1.15 PFLOP/s instead of one batched launch at 1.0
                 for j in range(3):
-                    torch.mm(mixed[j], lw.rkv[j].t(), out=rkv[j])
+                    torch.mm(mixed[j], w_rkv[j].t(), out=rkv[j])
             else:
-                rkv = torch.bmm(mixed[0:3], lw.rkv.transpose(1, 2))
+                rkv = torch.bmm(mixed[0:3], w_rkv.transpose(1, 2))
             if side is not None:
                 main.wait_stream(side)
                 for t_ in ([hid] if hid is not None else []) + (list(up) if isinstance(up, list) else [up]):
@@ -575,7 +662,7 @@ class RWKV_x070:
                 ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
                                prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts, mm8_out=q8_out)
             else:
-                att = F.linear(o_in, lw.O)
+                att = F.linear(o_in, w_O)
                 ops.add_ln_mix(B, T, C, x, att, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
                                prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, mm8_out=q8_out)
             if T > 1:
@@ -604,10 +691,10 @@ class RWKV_x070:
                         kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
                         kv2, xin = kf.view(rows, 4 * C), kin[0].view(rows, C)
                         half = (rows + 1) // 2
-                        torch.mm(xin[:half], lw.f_K.t(), out=kv2[:half])
-                        torch.mm(xin[half:], lw.f_K.t(), out=kv2[half:])
+                        torch.mm(xin[:half], w_fK.t(), out=kv2[:half])
+                        torch.mm(xin[half:], w_fK.t(), out=kv2[half:])
                     else:
-                        kf = F.linear(kin[0], lw.f_K)
+                        kf = F.linear(kin[0], w_fK)
                     ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
@@ -617,7 +704,7 @@ class RWKV_x070:
                     # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
                     dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), gs["ffn_value"], pbuf, row_halves=rh["ffn_value"]), None
                 else:
-                    delta = kf @ lw.f_V
+                    delta = kf @ w_fV
         if dparts is not None and (T > 1 and not full_output):
             delta, dparts = dparts.sum(0).to(DTYPE).view(B, T, C), None      # e.g. B=2, T=100: only the last rows are needed
         if T > 1 and not full_output:
@@ -631,12 +718,12 @@ class RWKV_x070:
             xo = xo.view(B, C)
         if slot_idx is not None:
             s2.index_add_(0, idx64, torch.full((B,), T, dtype=s2.dtype, device=s2.device))
-        if hw and self.skinny_head and xo.shape[0] <= 256:
+        if (hw or not self.keep_row_major) and self.skinny_head and xo.shape[0] <= 256:
             if self._head_t is None:
                 hwt = z["head.weight"]
                 self._head_t = ops.tile_weight(hwt) if (self.tiled_weights and hwt.shape[0] % 128 == 0 and hwt.shape[1] % 64 == 0) else hwt
             return ops.skinny_linear(xo, self._head_t, splits=1)
-        return F.linear(xo, z["head.weight"])
+        return F.linear(xo, self._head_row_major())
 
     def _tmix(self, layer_id, lw: _Layer, x, x_prev, v_first, S, elapsed_t):
         """Time-mix block, arithmetic of RWKV_x070_TMix_seq_batch (rwkv7.py:618-649).

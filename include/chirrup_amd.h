@@ -290,13 +290,15 @@ int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, 
  * a second launch behind them (round 2: 12 us per layer at 7.2B / bsz 200).
  *   main[i]  (n_main <= 4):  y = x . w^T                                        (as chirrup_gemm_problem; act as there)
  *   lora[p]  (n_lora <= 4):  hid = act(x . w^T)  [M][n of ld_hid], then  y = hid[:, :k_up] . w_up^T + bias  [M][up_n of up_ldy]
- * 32 < M <= 256 rows, shared K (% 64), ldx; w of lora[p] row-major [n][K] (row stride ldw, n % 64 == 0); w_up a tile image
+ * 1 <= M <= 256 rows (row_halves = 1 and M > 32: two workgroups per tile over the two halves of the rows, as elsewhere; whole-row
+ * tiles otherwise, M <= 128 -- at <= 32 rows the main tiles are then split 2..4 ways over K and reduced inside the launch like
+ * skinny_gemm_f16's), shared K (% 64), ldx; w of lora[p] row-major [n][K] (row stride ldw, n % 64 == 0); w_up a tile image
  * (skinny_tile_weight) of [up_n][up_kimg] whose first k_up columns are multiplied (k_up <= n, % 64); act: 0 none, 2 tanh,
  * 3 sigmoid.  workspace: rwkv7_tmix_gemms_workspace_bytes bytes; sync: rwkv7_tmix_sync_words() ints -- both hipMalloc'ed, sync
  * ZERO before the first launch (every completed launch leaves it zero; the workgroups hand tiles to each other through it with
  * write-through stores, one agent-scope atomic per workgroup and ONE agent-scope acquire per consumer: cdna_hip_programming.md
  * Guideline 16).  Every wait is bounded (spin_limit polls of ~0.25 us, 0 = default ~0.1 s): if one gives up -- another tenant
- * held most of the chip that long -- the LAST sync word is set non-zero and this launch's LoRA outputs are undefined.
+ * held most of the chip that long -- sync[rwkv7_tmix_status_word()] is set non-zero and this launch's LoRA outputs are undefined.
  * One launch at a time per (workspace, sync).
  */
 typedef struct {
@@ -309,16 +311,21 @@ typedef struct {
     int n, k_up, act;
 } chirrup_lora_problem;
 int rwkv7_tmix_sync_words(void);
-int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_lora, const chirrup_lora_problem *lora);
+int rwkv7_tmix_status_word(void);
+int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
+                                         const chirrup_lora_problem *lora, int row_halves);
 int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
-                     const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, void *workspace, void *sync,
-                     int spin_limit, void *stream);
+                     const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves, void *workspace,
+                     void *sync, int spin_limit, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight
  * 128-B pieces of eight rows K*2 bytes apart.  Wt: N*K elements, must not overlap W.  The row-major matrix is still
  * what every other consumer (library GEMMs of the prefill path) needs. */
 int skinny_tile_weight(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream);
+/* ... and back: the row-major matrix (row stride ldw) of a tile image, for callers that keep only the images and need a
+ * row-major operand now and then (library GEMMs of prefill chunks above 256 rows). */
+int skinny_untile_weight(int N, int K, const void *Wt, void *W, int64_t ldw, void *stream);
 /* The same for mm8t_seq's uint8 weights wT [M_out][N_in] (N = M_out, K = N_in): 8-KiB tile images, w_tiled = 1 there. */
 int skinny_tile_weight_u8(int N, int K, const void *W, int64_t ldw, void *Wt, void *stream);
 

@@ -122,3 +122,63 @@ def test_engine_process_mode_on_the_gpu_matches_thread_mode(tmp_path):
     assert all(len(x) == 10 for x in ids_p)
     assert ids_p == ids_t
     assert extra["resumed"] == extra["first"] == ids_p[1][:6]
+
+
+def test_process_mode_prefix_states_never_leave_hbm(tmp_path):
+    """VERDICT r2 item 4.  Two worker PROCESSES on cuda:0, each with its own HBM arena (state_arena_rows): a prefill exported by
+    one of them reaches the engine process as a row address (no tensor), is cached there, and every hit -- queued without
+    affinity ("avoid": queued for the process that does NOT own the row) -- is installed by a device copy out of the owner's arena
+    (opened through a HIP IPC handle in the other process).  The resumed streams equal the uncached stream's tail, the engine
+    counts local and cross-process installs, eviction hands rows back.  No state byte travels through host memory: the only
+    objects that cross a process boundary are (worker id, row) pairs -- asserted on the events -- and the arenas' IPC handles."""
+    from chirrup_amd.core_structure import ModelLoadConfig
+    from chirrup_amd.engine_core import AsyncEngineCore
+    from chirrup_amd.remote_arena import RemoteStateRef
+    from chirrup_amd.state_cache import SimpleStateCache
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    ckpt = os.path.join(tmp_path, "tiny.pth")
+    torch.save(zd, ckpt)
+    vocab = os.path.join(G, "mini_vocab.txt")
+    kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[])
+    texts = ["abc abc abc abc abc abc abc abc", "the quick brown fox jumps over the lazy dog", "a b c d e f g h i j k l m n"]
+
+    async def run(affinity):
+        eng = AsyncEngineCore(worker_mode="process", state_arena_rows=4, prefix_affinity=affinity, gpu_ids=[0, 0])
+        cfg = ModelLoadConfig(model_path=ckpt, vocab_path=vocab, vocab_size=320, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=2, model_config=cfg, batch_size=4), 300)
+        cache = SimpleStateCache(max_size=2, arena=eng.state_arena)
+        first = {}
+        for text in texts[:2]:
+            toks = eng.tokenizer.encode(text)
+            c = eng.completion("", prefill_tokens=list(toks), max_tokens=8, cache_prefill=True, cache_prefill_padding=2, **kw)
+            evs = [ev async for ev in c]
+            hit = [e[1] for e in evs if e[0] == "cache_prefill"]
+            assert len(hit) == 1 and isinstance(hit[0]["state"], RemoteStateRef)          # an address: (worker id, row)
+            cache.cache(hit[0]["prefilled_tokens"], hit[0]["state"])
+            first[text] = [e[1] for e in evs if e[0] == "token"]
+        for _ in range(3):
+            cs = []
+            for text in texts[:2] * 3:
+                toks = eng.tokenizer.encode(text)
+                rest, state, n_hit = cache.check(list(toks))
+                assert isinstance(state, RemoteStateRef) and n_hit == len(toks) - 2
+                cs.append((text, eng.completion("", prefill_tokens=rest, state=state, max_tokens=8, **kw)))
+            for text, c in cs:
+                assert [ev[1] async for ev in c if ev[0] == "token"] == first[text]      # resumed from the arena row: the same ids
+        inst = dict(eng._router.installs)
+        assert inst["local"] + inst["peer"] == 18
+        toks = eng.tokenizer.encode(texts[2])
+        c = eng.completion("", prefill_tokens=list(toks), max_tokens=2, cache_prefill=True, cache_prefill_padding=2, **kw)
+        hit = [e[1] for e in [ev async for ev in c] if e[0] == "cache_prefill"][0]
+        cache.cache(hit["prefilled_tokens"], hit["state"])
+        assert len(eng.state_arena.freed) == 1                                           # the evicted prefix's row went back to its worker
+        eng.shutdown()
+        return inst
+
+    a = asyncio.run(run(True))
+    b = asyncio.run(run("avoid"))
+    print("installs with affinity", a, "queued for the non-owner", b)
+    assert a["local"] > 0
+    assert b["peer"] > 0                    # another process copied rows out of the owner's arena through its IPC handle

@@ -436,16 +436,23 @@ def test_in_launch_pair_reduction_of_a_grouped_launch():
         assert int(ops._tile_counters(mixed.device).abs().sum()) == 0
 
 
-@pytest.mark.parametrize("M,C,ranks,p0", [(200, 4096, [128, 128, 128, 512], 0), (200, 4096, [128, 128, 128, 512], 1),
-                                          (130, 2048, [64, 128, 128, 256], 0), (256, 1024, [64, 64, 64, 192], 0), (40, 768, [64, 64, 64, 128], 1)])
-def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0):
+@pytest.mark.parametrize("M,C,ranks,p0,halves", [(200, 4096, [128, 128, 128, 512], 0, True), (200, 4096, [128, 128, 128, 512], 1, True),
+                                                 (130, 2048, [64, 128, 128, 256], 0, True), (256, 1024, [64, 64, 64, 192], 0, True),
+                                                 (40, 768, [64, 64, 64, 128], 1, True), (64, 4096, [128, 128, 128, 512], 0, False),
+                                                 (64, 4096, [128, 128, 128, 512], 0, True), (32, 2048, [128, 128, 64, 256], 0, False),
+                                                 (17, 2048, [128, 128, 64, 256], 1, False), (1, 768, [64, 64, 64, 128], 0, False),
+                                                 (128, 2048, [128, 128, 64, 256], 0, False)])
+def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0, halves):
     """rwkv7_tmix_gemms: R/K/V and the whole LoRA chain (down-projections, tanh / sigmoid, up-projections + bias) in ONE launch,
     the chain on the CUs the R/K/V tiles leave idle, its stages handed from workgroup to workgroup inside the launch.  Against
     the two launches it replaces (skinny_group + skinny_bmm): R/K/V bit-identical (the same unsplit sums); the hidden planes
     differ only by the binary32 order of a 4-way K split (<= 1 binary16 ulp before the activation); the up-projections within
     the GEMM bar of binary64.  hid / outputs are poisoned with NaN before every launch, so a consumer that read a tile before its
     producer published it shows as NaN; repeated 20 times, with a competing memory stream on another stream in half of the
-    runs (uneven load); every hand-off word is back at zero and the status word clear after each launch."""
+    runs (uneven load); every hand-off word is back at zero and the status word clear after each launch.
+    halves=False: whole-row tiles (<= 128 rows); at <= 32 rows the R/K/V tiles are then split over K and reduced inside the launch
+    (the bits of skinny_group's in-launch reduction at the same split count are not asserted here: the split is the library's
+    choice; the values are held to the GEMM bar)."""
     from chirrup_amd import ops
 
     torch.manual_seed(M + C + p0)
@@ -467,8 +474,8 @@ def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0):
         hid = torch.zeros(nz, M, dmax, device="cuda", dtype=torch.float16)
         probs = [(mixed[j], rkv_w[j], rkv[j], None, None) for j in range(3)]
         probs += [(mixed[2 + j], lora1[j, :ranks[j]], hid[j - p0, :, :ranks[j]], None, acts[j]) for j in range(p0, 4)]
-        ops.skinny_group(probs, splits=1, row_halves=True)            # unsplit: the sums the chain launch's R/K/V tiles form too
-        up = ops.skinny_bmm(hid, lora2_t[p0:], lbias[p0:], splits=1, k_of=ranks[p0:], row_halves=True)
+        ops.skinny_group(probs, splits=1, row_halves=halves)          # unsplit: the sums the chain launch's R/K/V tiles form too
+        up = ops.skinny_bmm(hid, lora2_t[p0:], lbias[p0:], splits=1, k_of=ranks[p0:], row_halves=halves)
         return rkv, hid, up
 
     want_rkv, want_hid, want_up = old()
@@ -490,12 +497,16 @@ def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 noise.add_(1)                                   # a competing kernel while the launch runs
-        ops.tmix_gemms(main_p, lora_p, lora2_t[p0:], hid)
+        ops.tmix_gemms(main_p, lora_p, lora2_t[p0:], hid, row_halves=halves)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         assert ops.chain_status() == 0
         assert all(int(t.abs().sum()) == 0 for t in ops._chain_sync.values())
-        assert torch.equal(rkv, want_rkv)
+        if halves or M > 32:
+            assert torch.equal(rkv, want_rkv)                   # unsplit R/K/V tiles: the same sums
+        else:                                                   # split over K and reduced in the launch: another binary32 order
+            assert not bool(torch.isnan(rkv).any())
+            assert float((rkv.float() - want_rkv.float()).abs().max()) <= 2e-3 * max(1.0, float(want_rkv.float().abs().max()))
         for j in range(p0, 4):
             z, r = j - p0, ranks[j]
             got_h, want_h = hid[z, :, :r].float(), want_hid[z, :, :r].float()

@@ -9,6 +9,7 @@ import torch
 from chirrup_amd import lib, ops
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+HALVES = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
 C = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ranks = {4096: [128, 128, 128, 512], 2048: [128, 128, 64, 256], 768: [64, 64, 64, 128]}[C]
 dev = "cuda"
@@ -36,7 +37,7 @@ def run(s):
     rkv_w, lora1, lora2_t = s
     main_p = [(mixed[j], rkv_w[j], rkv[j]) for j in range(3)]
     lora_p = [(mixed[2 + j], lora1[j, :ranks[j]], j, lbias[j].view(-1), up[j], acts[j], ranks[j]) for j in range(4)]
-    ops.tmix_gemms(main_p, lora_p, lora2_t, hid)
+    ops.tmix_gemms(main_p, lora_p, lora2_t, hid, row_halves=HALVES)
 
 
 for _ in range(3):
