@@ -286,7 +286,7 @@ def clock_probes(model, B):
     dev = model.device
     out = {}
     buf = torch.zeros((2,), dtype=torch.int64, device=dev)
-    L_.chirrup_clock_probe(4_000_000, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    L_.chirrup_clock_probe(200_000, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     t = buf.tolist()
     out["idle_mhz"] = round(t[0] / max(t[1], 1) * 100.0, 1)
@@ -327,7 +327,7 @@ def clock_probes(model, B):
 
 def gemm_roofline_object(timings, L):
     traffic = {}
-    for name in ("r02_gemm_pmc_traffic.json", "r02b_gemm_pmc_traffic.json"):       # r02b: the shapes that changed since (row halves)
+    for name in ("r02_gemm_pmc_traffic.json", "r02b_gemm_pmc_traffic.json", "r03_gemm_pmc_traffic.json"):   # later files: the shapes that changed since
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
             for shape, rec in json.load(open(f))["shapes"].items():
@@ -339,7 +339,7 @@ def gemm_roofline_object(timings, L):
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic.get(name), "what": what,
                         "launches_per_step": 1 if name == "head" else L}
     return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "bytes": "algorithmic: weight + x + y (fp16); split-K partials are not counted; traffic = HBM read + written bytes incl. partials (profiles/r02_gemm_pmc_traffic.json, r02b_...)",
+            "bytes": "algorithmic: weight + x + y (fp16); split-K partials are not counted; traffic = HBM read + written bytes incl. partials (profiles/r02_gemm_pmc_traffic.json, r02b_..., r03_...)",
             "shapes": shapes}
 
 

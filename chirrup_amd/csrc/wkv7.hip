@@ -87,6 +87,12 @@ struct TmixArgs {
     const f16 *g;          // [B,T,C]
     const f16 *k_k, *k_a, *r_k, *lnx_w, *lnx_b;   // [C]
     float eps;
+    // mm8 (w8a16) att.output: the kernel's output o feeds a uint8 GEMM in the split form of scripts/test_mm8/benchmark.py:
+    // 167-179, whose activation prologue is xs = binary16(o * ry) and the row sums {sum xs, sum o*my, sum o}.  With q_ry set the
+    // kernel stores xs INSTEAD of o and this head's share of the three sums: q_S[row][head][3] (the consumer adds the H parts
+    // in head order -- rwkv7_add_ln_mix_mm8, in_S_parts = H).
+    const f16 *q_ry, *q_my;    // [C] or nullptr
+    float *q_S;                // [B*T][H][3]
 };
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     int64_t o = (int64_t)bb * T * C + (int64_t)h * 64 + lane;
     f16 rj = r_[o], wj = w_[o], kj = k_[o], vi = v_[o];
     f16 aj, bj, gj = (f16)0.f, vgj = (f16)0.f, vfj = (f16)0.f;     // MODE 1: aj carries a_pre
-    f16 p_kk = (f16)0.f, p_ka = (f16)0.f, p_rk = (f16)0.f, p_lw = (f16)0.f, p_lb = (f16)0.f;
+    f16 p_kk = (f16)0.f, p_ka = (f16)0.f, p_rk = (f16)0.f, p_lw = (f16)0.f, p_lb = (f16)0.f, p_ry = (f16)0.f, p_my = (f16)0.f;
     if (MODE == 0) {
         aj = a_[o];
         bj = b_[o];
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
         gj = tm.g[o];
         if (tm.v_first) { vgj = tm.vg_pre[o]; vfj = tm.v_first[o]; }
         p_kk = tm.k_k[ch]; p_ka = tm.k_a[ch]; p_rk = tm.r_k[ch]; p_lw = tm.lnx_w[ch]; p_lb = tm.lnx_b[ch];
+        if (tm.q_ry) { p_ry = tm.q_ry[ch]; p_my = tm.q_my[ch]; }
     }
     const int32_t et = elapsed_t[bb];
 
@@ -233,7 +240,18 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
             const float rstd = 1.0f / sqrtf(wave_sum(dlt * dlt) * (1.0f / 64.0f) + tm.eps);
             const float gn = (float)hf(dlt * rstd * (float)p_lw + (float)p_lb);
             const float bonus = (float)hf(wave_sum((float)hf((float)hf((float)r_cur * (float)k_in) * (float)p_rk)));
-            y_[o_cur] = hf((float)hf(gn + (float)hf(bonus * (float)vv)) * (float)g_cur);
+            const f16 out = hf((float)hf(gn + (float)hf(bonus * (float)vv)) * (float)g_cur);
+            if (tm.q_ry) {                                  // mm8 prologue of att.output (mm8_prep_kernel's arithmetic)
+                const f16 xs = hf((float)out * (float)p_ry);
+                const float s0 = wave_sum((float)xs), s1 = wave_sum((float)out * (float)p_my), s2 = wave_sum((float)out);
+                y_[o_cur] = xs;
+                if (lane == 0) {
+                    float *dst = tm.q_S + (((int64_t)bb * T + t) * H + h) * 3;
+                    dst[0] = s0, dst[1] = s1, dst[2] = s2;
+                }
+            } else {
+                y_[o_cur] = out;
+            }
         }
         __builtin_amdgcn_s_barrier();  // strip is rewritten next iteration
     }
@@ -340,14 +358,28 @@ extern "C" int rwkv7_tmix_wkv7_fused(int B, int T, int C, int H, void *state, co
                                      const void *r_k, const void *lnx_w, const void *lnx_b, float eps, void *out,
                                      const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride,
                                      void *stream) {
+    return rwkv7_tmix_wkv7_fused_mm8(B, T, C, H, state, r, w, k, v, a_pre, vg_pre, v_first, g, k_k, k_a, r_k, lnx_w, lnx_b, eps, out,
+                                     elapsed_t, slot_idx, slot_stride, nullptr, nullptr, nullptr, stream);
+}
+
+// ... with the mm8 activation prologue of the GEMM that consumes `out` (att.output as uint8 weights): out receives
+// xs = binary16(o * ry), S [B*T][H][3] this head's shares of {sum xs, sum o*my, sum o}.  ry == NULL: the plain form.
+extern "C" int rwkv7_tmix_wkv7_fused_mm8(int B, int T, int C, int H, void *state, const void *r, const void *w,
+                                         const void *k, const void *v, const void *a_pre, const void *vg_pre,
+                                         const void *v_first, const void *g, const void *k_k, const void *k_a,
+                                         const void *r_k, const void *lnx_w, const void *lnx_b, float eps, void *out,
+                                         const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride,
+                                         const void *ry, const void *my, float *S, void *stream) {
     const int rc = check_args(B, T, C, H, state, r, w, k, v, a_pre, g, out, elapsed_t, slot_stride);
     if (rc != CHIRRUP_OK) return rc;
     if (!k_k || !k_a || !r_k || !lnx_w || !lnx_b) return CHIRRUP_E_NULL;
     if ((vg_pre == nullptr) != (v_first == nullptr)) return CHIRRUP_E_NULL;
+    if (ry && (!my || !S)) return CHIRRUP_E_NULL;
     if (slot_stride == 0) slot_stride = (int64_t)H * 4096;
     TmixArgs tm{static_cast<const f16 *>(a_pre), static_cast<const f16 *>(vg_pre), static_cast<const f16 *>(v_first),
                 static_cast<const f16 *>(g), static_cast<const f16 *>(k_k), static_cast<const f16 *>(k_a),
-                static_cast<const f16 *>(r_k), static_cast<const f16 *>(lnx_w), static_cast<const f16 *>(lnx_b), eps};
+                static_cast<const f16 *>(r_k), static_cast<const f16 *>(lnx_w), static_cast<const f16 *>(lnx_b), eps,
+                static_cast<const f16 *>(ry), static_cast<const f16 *>(my), S};
     hipLaunchKernelGGL(wkv7_seq_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
                        static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
                        static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v), nullptr, nullptr,

@@ -109,6 +109,7 @@ class AsyncEngineCore:
             from .remote_arena import RemoteArena
 
             kwargs["state_arena_rows"] = self.state_arena_rows
+            kwargs["arena_steal"] = self.prefix_affinity != "avoid"      # ("avoid": tests -- the owner must not take its hits back)
             self.state_arena = RemoteArena(self.state_arena_rows, worker_num, self._send_arena_free)
         self._router = ep.ResultRouter(self._result_q, self.worker_event_queue, self._on_process_worker_exit, self.state_arena)
         self.workers, affinity_qs = ep.spawn_workers(worker_num, model_config, batch_size, self._worker_factory, kwargs,

@@ -101,8 +101,8 @@ class RemoteTaskQueue:
 
     EARLY_ABORTS = 4096                                 # ids remembered for tasks nobody has pulled yet (oldest dropped first)
 
-    def __init__(self, task_q, result_q, worker_id: str, affinity_qs: Optional[Dict[str, Any]] = None):
-        self._q, self._result_q, self._wid = task_q, result_q, worker_id
+    def __init__(self, task_q, result_q, worker_id: str, affinity_qs: Optional[Dict[str, Any]] = None, steal: bool = True):
+        self._q, self._result_q, self._wid, self._steal = task_q, result_q, worker_id, steal
         self._affinity = dict(affinity_qs or {})        # worker id -> queue of hits on rows of that worker's arena
         self.arena = None                               # set by the worker once it has built its arena
         self.local_events: Dict[str, queue.Queue] = {}
@@ -122,7 +122,7 @@ class RemoteTaskQueue:
             return self._q.get_nowait()
         except queue.Empty:
             pass
-        for wid, q_ in self._affinity.items():
+        for wid, q_ in (self._affinity.items() if self._steal else ()):
             if wid != self._wid:
                 try:
                     return q_.get_nowait()
@@ -168,8 +168,8 @@ def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLo
                         control_q, abort_q, worker_factory: Optional[Callable[..., Any]], worker_kwargs: Dict[str, Any],
                         affinity_qs: Optional[Dict[str, Any]] = None, peer_qs: Optional[Dict[str, Any]] = None) -> None:
     """Entry point of a worker process (spawned: nothing of the parent's CUDA/HIP state is inherited)."""
-    tasks = RemoteTaskQueue(task_q, result_q, worker_id, affinity_qs)
     worker_kwargs = dict(worker_kwargs)
+    tasks = RemoteTaskQueue(task_q, result_q, worker_id, affinity_qs, steal=worker_kwargs.pop("arena_steal", True))
     if worker_kwargs.get("state_arena_rows", 0) > 0 and peer_qs:
         import torch.multiprocessing  # noqa: F401 -- registers the tensor reductions (IPC handles) with multiprocessing's pickler
 

@@ -197,6 +197,15 @@ int rwkv7_tmix_wkv7_fused(int B, int T, int C, int H, void *state, const void *r
                           const void *k_k, const void *k_a, const void *r_k, const void *lnx_w, const void *lnx_b,
                           float eps, void *out, const int32_t *elapsed_t, const int32_t *slot_idx,
                           int64_t slot_stride, void *stream);
+/* ... with the mm8 (w8a16) activation prologue of the GEMM that consumes `out` (att.output as uint8 weights, scripts/test_mm8/
+ * benchmark.py:167-173, :447-452): out receives xs = binary16(o * ry) instead of o, and S [B*T][H][3] (float) each head's share of
+ * the row sums {sum xs, sum o*my, sum o} (the consumer adds the H parts in head order: rwkv7_add_ln_mix_mm8 with in_S_parts = H).
+ * ry = NULL: identical to rwkv7_tmix_wkv7_fused. */
+int rwkv7_tmix_wkv7_fused_mm8(int B, int T, int C, int H, void *state, const void *r, const void *w, const void *k, const void *v,
+                              const void *a_pre, const void *vg_pre, const void *v_first, const void *g, const void *k_k,
+                              const void *k_a, const void *r_k, const void *lnx_w, const void *lnx_b, float eps, void *out,
+                              const int32_t *elapsed_t, const int32_t *slot_idx, int64_t slot_stride, const void *ry,
+                              const void *my, float *S, void *stream);
 
 /* rwkv7.py:678: x <- relu(x)**2 in place over n elements (n % 8 == 0). */
 int rwkv7_relu_sq(int64_t n, void *x, void *stream);

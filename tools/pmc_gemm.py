@@ -2,7 +2,8 @@
 `rocprofv3 --pmc ...` can attribute counters to it.  The calls are the model's own (tile-image weights, same splits).
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d <dir> -- python3 tools/pmc_gemm.py ffn.value
-shapes: ffn.key | ffn.value | att.output | rkv_lora (the grouped launch) | lora_up | head | ffn.key.u8 | ffn.value.u8
+shapes: ffn.key | ffn.value | att.output | tmix_chain (R/K/V + the LoRA chain, one launch) | rkv_lora (the grouped launch it
+        replaced) | lora_up | head | ffn.key.u8 | ffn.value.u8
 (ffn.key, att.output and lora_up as shipped: two workgroups per tile over the two halves of the rows)
 """
 import os
@@ -46,6 +47,25 @@ elif shape == "rkv_lora":
             kj = (ranks[j] + 63) // 64 * 64
             probs.append((mixed[2 + j], W[1][j][:kj], hid[j, :, :kj], None, "tanh" if j == 1 else None))
         ops.skinny_group(probs, splits=2)
+elif shape == "tmix_chain":
+    # the shipped time-mix launch: R/K/V tiles + the whole LoRA chain (rwkv7_tmix_gemms), row halves
+    ranks = (128, 128, 128, 512)
+    Ws = []
+    for _ in range(NW):
+        l1 = torch.zeros(4, 512, C, device=dev, dtype=torch.float16)
+        l2 = torch.zeros(4, C, 512, device=dev, dtype=torch.float16)
+        for j, r in enumerate(ranks):
+            l1[j, :r], l2[j, :, :r] = rnd(r, C), rnd(C, r)
+        Ws.append(([ops.tile_weight(rnd(C, C)) for _ in range(3)], l1, ops.tile_weight_batch(l2)))
+    mixed = torch.randn(6, M, C, device=dev).half()
+    rkv, hid = torch.empty(3, M, C, device=dev, dtype=torch.float16), torch.empty(4, M, 512, device=dev, dtype=torch.float16)
+    up, lb = torch.empty(4, M, C, device=dev, dtype=torch.float16), torch.randn(4, 1, C, device=dev).half()
+
+    def run(W):
+        main_p = [(mixed[j], W[0][j], rkv[j]) for j in range(3)]
+        lora_p = [(mixed[2 + j], W[1][j, :ranks[j]], j, lb[j].view(-1), up[j], "tanh" if j == 1 else ("sigmoid" if j == 3 else None), ranks[j])
+                  for j in range(4)]
+        ops.tmix_gemms(main_p, lora_p, W[2], hid, row_halves=True)
 elif shape == "lora_up":
     ranks = [128, 128, 128, 512]
     Ws = [ops.tile_weight_batch((torch.randn(4, C, 512, device=dev) / 512 ** 0.5).half()) for _ in range(NW * 2)]
