@@ -47,6 +47,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     p.add_argument("--no-fused", action="store_true", help="plain torch ops around the WKV7 kernel")
     p.add_argument("--mm8", action="store_true", help="uint8 (w8a16) channel-mix weights through the MFMA mm8 kernel")
+    p.add_argument("--mm8-all", action="store_true", help="uint8 (w8a16) weights for every matrix scripts/test_mm8/benchmark.py:447-452 lists: R/K/V/O, ffn.key, ffn.value, head")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mm8-leg", action="store_true", help="skip the second (uint8 FFN) model of the mm8 object")
     p.add_argument("--no-engine-leg", action="store_true", help="skip the Worker-loop measurement of the engine object")
@@ -75,14 +76,14 @@ def parse():
     return p.parse_args()
 
 
-def build_model(name, device, fused, mm8=False, tiled=True, min_embd=None):
+def build_model(name, device, fused, mm8=False, tiled=True, min_embd=None, att8=False):
     from chirrup_amd.rwkv7 import RWKV_x070, model_args
     from chirrup_amd.synth import CONFIGS, make_state_dict
 
     L, C = CONFIGS[name]
     zd = make_state_dict(L, C, 65536, seed=42, device=device)      # random-init weights of the architecture
     m = RWKV_x070(model_args("synthetic"), state_dict=zd, device=device, fused=fused,
-                  ffn_dtype=torch.int8 if mm8 else torch.float16, tiled_weights=tiled,
+                  ffn_dtype=torch.int8 if mm8 else torch.float16, att_dtype=torch.int8 if att8 else torch.float16, tiled_weights=tiled,
                   **({} if min_embd is None else {"skinny_min_embd": min_embd}))
     del zd
     torch.cuda.empty_cache()
@@ -555,7 +556,7 @@ def main():
 
     L, C = CONFIGS[a.model]
     B = a.bsz
-    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
+    model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8 or a.mm8_all, tiled=not a.no_tiled, min_embd=a.skinny_min_embd, att8=a.mm8_all)
     if a.splits is not None:
         model.gemm_splits.update(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (int(v) for v in a.splits.split(","))))
     if a.row_halves is not None:
@@ -603,7 +604,7 @@ def main():
     gemm_t = gemm_shape_timings(model, B) if rank == 0 else {}
     clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
     mm8_obj = None
-    if rank == 0 and world == 1 and not a.mm8 and not a.no_mm8_leg and not a.no_fused:
+    if rank == 0 and world == 1 and not a.mm8 and not a.mm8_all and not a.no_mm8_leg and not a.no_fused:
         # the int8 channel-mix path north_star names: the same step with uint8 (w8a16) FFN weights (second model, same seed)
         del state
         m8 = build_model(a.model, dev, fused=True, mm8=True, tiled=not a.no_tiled, min_embd=a.skinny_min_embd)
@@ -640,7 +641,7 @@ def main():
             "metric": "decode tokens/sec (whole job) and tps/request, RWKV7-g1 " + a.model + f" bsz={B}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if not a.mm8 else "f16 (u8 ffn weights, mm8)", "data": "synthetic",
+            "dtype": "f16" if not (a.mm8 or a.mm8_all) else ("f16 (u8 ffn weights, mm8)" if not a.mm8_all else "f16 (u8 weights for R/K/V/O, ffn and head: mm8)"), "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
                                    "greedy decode step incl. " + ("plain arg-max" if a.no_penalties else "the worker's penalty tables, fused arg-max and device-side id commit") + " and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",

@@ -361,8 +361,10 @@ def tmix_post(rows: int, C: int, y, r, k, v, g, r_k, lnx_w, lnx_b, eps: float, o
 
 
 def tmix_wkv7_fused(B: int, T: int, C: int, H: int, state, r, w, k, v, a_pre, vg_pre, v_first, g, k_k, k_a, r_k, lnx_w,
-                    lnx_b, eps: float, out, elapsed_t, slot_idx=None) -> None:
-    """Gating + WKV7 + group-norm/bonus/gate in one kernel (include/chirrup_amd.h: rwkv7_tmix_wkv7_fused)."""
+                    lnx_b, eps: float, out, elapsed_t, slot_idx=None, mm8_out=None) -> None:
+    """Gating + WKV7 + group-norm/bonus/gate in one kernel (include/chirrup_amd.h: rwkv7_tmix_wkv7_fused).
+    mm8_out = (ry [C], my [C], S fp32 [B*T, H, 3]): `out` receives the mm8 activation prologue xs = fp16(o * ry) of the uint8
+    GEMM that consumes it (att.output) and S each head's share of its row sums (rwkv7_tmix_wkv7_fused_mm8)."""
     if H * HEAD_SIZE != C:
         raise _lib.ChirrupAmdError(f"H*64 != C ({H}*64 != {C})")
     _chk(state, "state", torch.float16)
@@ -377,9 +379,15 @@ def tmix_wkv7_fused(B: int, T: int, C: int, H: int, state, r, w, k, v, a_pre, vg
         _chk(slot_idx, "slot_idx", torch.int32, (B,))
     elif n_slots != B:
         raise _lib.ChirrupAmdError(f"state has {n_slots} slots for batch {B} and no slot_idx")
-    rc = _lib.load().rwkv7_tmix_wkv7_fused(B, T, C, H, state.data_ptr(), _ptr(r), _ptr(w), _ptr(k), _ptr(v), _ptr(a_pre),
-                                           _ptr(vg_pre), _ptr(v_first), _ptr(g), _ptr(k_k), _ptr(k_a), _ptr(r_k), _ptr(lnx_w),
-                                           _ptr(lnx_b), eps, _ptr(out), elapsed_t.data_ptr(), _ptr(slot_idx), 0, _stream())
+    ry = my = S = None
+    if mm8_out is not None:
+        ry, my, S = mm8_out
+        _chk16("mm8_out ry", ry, C), _chk16("mm8_out my", my, C)
+        _chk(S, "mm8_out S", torch.float32, (B * T, H, 3))
+    rc = _lib.load().rwkv7_tmix_wkv7_fused_mm8(B, T, C, H, state.data_ptr(), _ptr(r), _ptr(w), _ptr(k), _ptr(v), _ptr(a_pre),
+                                               _ptr(vg_pre), _ptr(v_first), _ptr(g), _ptr(k_k), _ptr(k_a), _ptr(r_k), _ptr(lnx_w),
+                                               _ptr(lnx_b), eps, _ptr(out), elapsed_t.data_ptr(), _ptr(slot_idx), 0, _ptr(ry), _ptr(my),
+                                               _ptr(S), _stream())
     _lib.check(rc, "rwkv7_tmix_wkv7_fused")
 
 

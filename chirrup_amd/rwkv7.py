@@ -86,7 +86,7 @@ class _Layer:
     __slots__ = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "x_r", "x_w", "x_k", "x_v", "x_a", "x_g", "w0", "w1", "w2", "a0", "a1",
                  "a2", "v0", "v1", "v2", "g1", "g2", "k_k", "k_a", "r_k", "R", "K", "V", "O", "lnx_w", "lnx_b", "f_x_k",
                  "f_K", "f_V", "mix6", "rkv", "lora1", "lora2", "lora_k", "lbias", "f_K8", "f_V8", "f_V_rows",
-                 "rkv_t", "O_t", "f_K_t", "f_V_t", "lora2_t", "f8_tiled")
+                 "rkv_t", "O_t", "f_K_t", "f_V_t", "lora2_t", "f8_tiled", "R8", "K8", "V8", "O8", "a8_tiled", "rkv8_ry", "rkv8_my")
 
     def __init__(self, z, i):
         b, a, f = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
@@ -167,6 +167,28 @@ class _Layer:
         self.f_K = self.f_V = None
 
 
+def _quantize_att(lw, z, i, tile: bool = False):
+    """mm8 (w8a16) time-mix projections: receptance / key / value / output quantised like the reference's quantize_weight
+    (scripts/test_mm8/benchmark.py:54-85; matrices named at :447-452); the binary16 copies are dropped.  z keeps
+    '<key>.mm8' -> Mm8Weight."""
+    from .quant import quantize_linear
+
+    a = f"blocks.{i}.att."
+    ws = [quantize_linear(w) for w in (lw.R, lw.K, lw.V, lw.O)]
+    lw.a8_tiled = False
+    if tile and all(w.qT.shape[0] % 128 == 0 and w.qT.shape[1] % 64 == 0 for w in ws):
+        ws = [w._replace(qT=ops.tile_weight_u8(w.qT)) for w in ws]
+        lw.a8_tiled = True
+    lw.R8, lw.K8, lw.V8, lw.O8 = ws
+    lw.rkv8_ry = torch.stack([w.ry for w in ws[:3]]).contiguous()     # [3, C]: the LN kernel writes the three prologues
+    lw.rkv8_my = torch.stack([w.my for w in ws[:3]]).contiguous()
+    for n, w in zip(("receptance", "key", "value", "output"), ws):
+        z[a + n + ".weight.mm8"] = w
+        del z[a + n + ".weight"]
+    lw.R = lw.K = lw.V = lw.O = lw.rkv = None
+    lw.rkv_t = lw.O_t = None
+
+
 class _LazyWeights(dict):
     """``.z`` of a tile-image-only model: the keys whose row-major tensors were freed are rebuilt from their tile images on
     every access (a new tensor each time -- for inspection and export, not for the hot path)."""
@@ -200,12 +222,16 @@ class RWKV_x070:
 
     def __init__(self, args, auto_load=True, state_dict: Optional[Dict[str, torch.Tensor]] = None, device=None,
                  fused: bool = True, wkv_impl: Optional[Callable] = None, ffn_dtype: torch.dtype = torch.float16,
-                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 0, keep_row_major: bool = True):
+                 sparse_bsz1: bool = False, tiled_weights: bool = True, skinny_min_embd: int = 0, keep_row_major: bool = True,
+                 att_dtype: torch.dtype = torch.float16):
         """keep_row_major=False: the six big matrices of every layer (and the head) live ONLY as tile images -- the row-major
         originals are freed after tiling (-12*C^2*2 B per layer: 12.9 GB at 7.2B, 24.6 GB at 13.3B, HBM that config 5 wants for
         cached states).  Forwards of more than 256 token rows (library GEMMs) then rebuild a layer's row-major operands into one
         reused scratch set first (skinny_untile_weight: +0.16 ms per layer at ~5 TB/s of copies, ~11 % of a 2500-row chunk);
-        the reference's keys stay readable in ``.z`` (rebuilt on access)."""
+        the reference's keys stay readable in ``.z`` (rebuilt on access).
+        att_dtype=torch.int8: receptance / key / value / output and the head as mm8 (w8a16) weights too -- with ffn_dtype=int8
+        every matrix scripts/test_mm8/benchmark.py:447-452 lists; half the weight bytes of a step, which is what the
+        HBM-bound batch sizes (<= 64 rows) are made of."""
         self.args = args
         self.tiled_weights = bool(tiled_weights)     # second, tile-image copies of the ring GEMM's matrices (_Layer.tile_for_ring)
         self.keep_row_major = bool(keep_row_major) or not tiled_weights
@@ -259,6 +285,12 @@ class RWKV_x070:
         self.row_halves_min_rows = 128
         self.gemm_row_halves = {"rkv": True, "att_out": True, "ffn_key": True, "ffn_value": False}
         self.ffn_dtype = ffn_dtype
+        self.att_dtype = att_dtype
+        if att_dtype not in (torch.float16, torch.int8):
+            raise ValueError("att_dtype must be torch.float16 or torch.int8 (mm8, w8a16)")
+        if att_dtype == torch.int8 and not (fused and self.device.type == "cuda"):
+            raise ops._lib.ChirrupAmdError("the mm8 time-mix path needs the HIP kernels (a GPU, fused=True)")
+        self.head8 = None
         # bsz = 1 decode: skip the rows of ffn.value whose relu^2 input is zero (the reference's
         # RWKV_x070_CMix_one + rwkv_mm_sparsity, rwkv7.py:653-662); needs the [4C, C] row layout, so it
         # keeps one extra copy of ffn.value per layer -- meant for the small single-stream configs
@@ -274,8 +306,20 @@ class RWKV_x070:
                     lw.quantize_ffn(self.z, i, tile=self.tiled_weights)
                 lw.f_V_rows = lw.f_V.contiguous() if self.sparse_bsz1 else None
                 lw.rkv_t = lw.O_t = lw.f_K_t = lw.f_V_t = lw.lora2_t = None
+                lw.R8 = lw.K8 = lw.V8 = lw.O8 = lw.rkv8_ry = lw.rkv8_my = None
+                lw.a8_tiled = False
                 if self.tiled_weights and self.n_embd >= self.skinny_min_embd:
                     lw.tile_for_ring()
+                if att_dtype == torch.int8:
+                    _quantize_att(lw, self.z, i, tile=self.tiled_weights)
+            if att_dtype == torch.int8:
+                from .quant import quantize_linear
+
+                h8 = quantize_linear(self.z["head.weight"])
+                self._head8_tiled = bool(self.tiled_weights and h8.qT.shape[0] % 128 == 0 and h8.qT.shape[1] % 64 == 0)
+                self.head8 = h8._replace(qT=ops.tile_weight_u8(h8.qT)) if self._head8_tiled else h8
+                self.z["head.weight.mm8"] = self.head8
+                del self.z["head.weight"]
             if not self.keep_row_major:
                 self._drop_row_major()
             torch.cuda.empty_cache()
@@ -524,12 +568,18 @@ class RWKV_x070:
         pbuf = (torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), dtype=torch.float32, device=dev)
                 if use_parts else None)
         pbuf_o = (torch.empty((ops.gemm_splits(C, C, 1, gs["att_out"]), rows, C), dtype=torch.float32, device=dev)
-                  if (hw and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)
+                  if (hw and self.skinny_att_out and rows >= self.skinny_wide_rows) else None)      # (also the uint8 att.output's core partials)
 
         # mm8 FFN in the decode regime: prologue / reduce launches of the two u8 products folded into the LN kernels and one
         # row-reduce kernel between them (same arithmetic as ops.mm8t_linear)
         q8 = hw and self.ffn_dtype == torch.int8 and T == 1
         dq = None                         # (rx, mx, S) of the mm8 product whose core partials `dparts` holds
+        # mm8 time-mix projections (att_dtype=int8).  Decode regime: att.output's activation prologue comes out of the fused
+        # time-mix core and its corrections are applied by LN2 (like ffn.value's by LN1); everything else -- and every
+        # projection outside the decode regime -- goes through mm8t_linear (prologue, uint8 MFMA GEMM, reduce).
+        a8 = self.att_dtype == torch.int8
+        a8_out_fused = a8 and hw and T == 1 and fuse_core and self.skinny_att_out
+        S_o = torch.empty((rows, H, 3), dtype=torch.float32, device=dev) if a8_out_fused else None
         if q8:
             f32 = dict(dtype=torch.float32, device=dev)
             xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
@@ -551,7 +601,7 @@ class RWKV_x070:
                 if not s0[i][j].is_contiguous():
                     raise ops._lib.ChirrupAmdError("state[0][layer][j] view must be contiguous (slice the batch dim only)")
             # library-GEMM operands (more than 256 rows): resident, or rebuilt from the tile images (keep_row_major=False)
-            w_rkv, w_O, w_fK, w_fV = (lw.rkv, lw.O, lw.f_K, lw.f_V) if (hw or lw.rkv is not None) else self._row_major(lw)
+            w_rkv, w_O, w_fK, w_fV = (lw.rkv, lw.O, lw.f_K, lw.f_V) if (hw or self.keep_row_major) else self._row_major(lw)
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
             upd = delta is not None or dparts is not None
@@ -567,7 +617,11 @@ class RWKV_x070:
             side = self._side if self.overlap_lora else None
             grouped = hw and self.group_tmix_gemms
             chained = (grouped and self.chain_tmix_gemms and ops.TMIX_CHAIN and rows >= self.chain_min_rows and (rh["rkv"] or rows <= 128)
-                       and lw.lora2_t is not None and lw.rkv_t is not None and not gs["rkv"])
+                       and lw.lora2_t is not None and lw.rkv_t is not None and not gs["rkv"] and not a8)
+            if a8:                                             # r, k, v through the uint8 weights
+                rkv = new(3, rows, C)
+                for j, w8 in enumerate((lw.R8, lw.K8, lw.V8)):
+                    ops.mm8t_linear(mixed[j], *w8, out=rkv[j], tiled=lw.a8_tiled)
             if chained:
                 # ONE launch for R/K/V AND the whole LoRA chain: down-projections, activations and up-projections run on the CUs
                 # the R/K/V tiles leave idle, beside them (chain_gemm_kernel) -- no second launch for the up-projections
@@ -582,10 +636,13 @@ class RWKV_x070:
             elif grouped:
                 # ONE launch for R/K/V and the LoRA down-projections (+ their activations in its reduce), then the
                 # LoRA up-projections, all on this stream: no cross-stream edges (they cost ~19 us per layer)
-                rkv = new(3, rows, C)
                 hid = new(4 - p0, rows, lw.lora1.shape[1])         # columns past a problem's rank are never read
-                wr = lw.rkv_t if lw.rkv_t is not None else lw.rkv
-                probs = [(mixed[j], wr[j], rkv[j], None, None) for j in range(3)]
+                if a8:
+                    probs = []
+                else:
+                    rkv = new(3, rows, C)
+                    wr = lw.rkv_t if lw.rkv_t is not None else lw.rkv
+                    probs = [(mixed[j], wr[j], rkv[j], None, None) for j in range(3)]
                 for j in range(p0, 4):
                     kj = lw.lora_k[j]
                     probs.append((mixed[2 + j], lw.lora1[j, :kj], hid[j - p0, :, :kj], None, ("tanh" if j == 1 else ("sigmoid" if j == 3 else None))))
@@ -620,7 +677,7 @@ class RWKV_x070:
                                         k_of=lw.lora_k[p0:])                                   # padding of the ranks not read
                 else:
                     up = torch.baddbmm(lw.lbias[p0:], hid, lw.lora2[p0:].transpose(1, 2))     # + v0 / w0 / a0 / 0
-            if grouped:
+            if grouped or a8:
                 pass
             elif hw and self.skinny_rkv:
                 rkv = ops.skinny_bmm(mixed[0:3], lw.rkv, splits=2)                             # one launch for R, K, V
@@ -642,7 +699,8 @@ class RWKV_x070:
             if fuse_core:
                 # gating + WKV7 + group-norm/bonus/gate in ONE kernel; k', v', -kk, kk*a, y never reach HBM
                 ops.tmix_wkv7_fused(B, T, C, H, s1[i], r, w, k, v, a_pre, vg_pre, v_first if i > 0 else None, g, lw.k_k,
-                                    lw.k_a, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in, elapsed, slot_idx)
+                                    lw.k_a, lw.r_k, lw.lnx_w, lw.lnx_b, 64e-5, o_in, elapsed, slot_idx,
+                                    mm8_out=(lw.O8.ry, lw.O8.my, S_o) if a8_out_fused else None)
                 if i == 0:
                     v_first = v
             else:
@@ -657,7 +715,17 @@ class RWKV_x070:
             # residual add of the time-mix + LN2 + token shift + one lerp
             prev = s0[i][1]
             q8_out = (lw.f_K8.ry, lw.f_K8.my, xs_k, S_k) if q8 else None
-            if hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
+            if a8_out_fused:
+                # o_in holds xs = fp16(o * ry): the uint8 GEMM's core partials, corrected by the LN kernel below (mm8_in)
+                aparts = ops.mm8t_gemm_partial(o_in.view(rows, C), lw.O8.qT, C, gs["att_out"], pbuf_o, tiled=lw.a8_tiled, row_halves=rh["att_out"])
+                ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts,
+                               mm8_in=(lw.O8.rx, lw.O8.mx, S_o), mm8_out=q8_out)
+            elif a8:
+                att = ops.mm8t_linear(o_in.view(rows, C), *lw.O8, tiled=lw.a8_tiled).view(B, T, C)
+                ops.add_ln_mix(B, T, C, x, att, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
+                               prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, mm8_out=q8_out)
+            elif hw and self.skinny_att_out and rows >= self.skinny_wide_rows:
                 aparts = ops.skinny_linear_partial(o_in.view(rows, C), lw.O_t if lw.O_t is not None else lw.O, gs["att_out"], pbuf_o, row_halves=rh["att_out"])   # reduce folded into the LN below
                 ops.add_ln_mix(B, T, C, x, None, x if T == 1 else x_alt, lw.ln2_w, lw.ln2_b, 1e-5, prev,
                                prev if T == 1 else carry, lw.f_x_k.view(1, C), kin, slot_idx, delta_partials=aparts, mm8_out=q8_out)
@@ -718,6 +786,8 @@ class RWKV_x070:
             xo = xo.view(B, C)
         if slot_idx is not None:
             s2.index_add_(0, idx64, torch.full((B,), T, dtype=s2.dtype, device=s2.device))
+        if self.head8 is not None:
+            return ops.mm8t_linear(xo.reshape(-1, C), *self.head8, tiled=self._head8_tiled).view(*xo.shape[:-1], -1)
         if (hw or not self.keep_row_major) and self.skinny_head and xo.shape[0] <= 256:
             if self._head_t is None:
                 hwt = z["head.weight"]

@@ -110,19 +110,28 @@ def _shift(x, prev):
     return np.concatenate([prev[:, None, :], x[:, :-1, :]], axis=1) - x
 
 
-def tmix(layer_id, H, x, x_prev, v_first, S, z, att, elapsed_t):
+def tmix(layer_id, H, x, x_prev, v_first, S, z, att, elapsed_t, att8=None, mm8_blas=False):
     """RWKV_x070_TMix_seq_batch, Albatross/rwkv7.py:618-649.  x [B,T,C]; x_prev = state[0][layer]
-    ([2,B,C], row 0 updated in place); S = state[1][layer] ([B,H,64,64], in place)."""
+    ([2,B,C], row 0 updated in place); S = state[1][layer] ([B,H,64,64], in place).
+    att8: {"receptance" | "key" | "value" | "output": (q [N,M], mx, rx, my, ry)} -- those projections through the as-coded
+    mm8 product (w8a16; the matrices scripts/test_mm8/benchmark.py:447-452 lists) instead of the binary16 weights."""
     B, T, C = x.shape
     N = C // H
     xx = _shift(x, x_prev[0])
     x_prev[0] = x[:, -1, :]
     g = lambda n: z[att + n]
+    mm = mm8_seq_blas if mm8_blas else native.mm8_seq
+
+    def proj(xin, name):
+        if att8 is not None and name in att8:
+            return mm(np.ascontiguousarray(xin.reshape(B * T, -1)), *att8[name]).reshape(B, T, -1)
+        return linear(xin, g(name + ".weight"))
+
     xr, xw, xk, xv, xa, xg = (x + xx * g(n) for n in ("x_r", "x_w", "x_k", "x_v", "x_a", "x_g"))
-    r = linear(xr, g("receptance.weight"))
+    r = proj(xr, "receptance")
     w = linear(tanh_h(linear(xw, g("w1"))), g("w2"), bias=g("w0"))
-    k = linear(xk, g("key.weight"))
-    v = linear(xv, g("value.weight"))
+    k = proj(xk, "key")
+    v = proj(xv, "value")
     a = sigmoid_h(linear(linear(xa, g("a1")), g("a2"), bias=g("a0")))
     gate = linear(sigmoid_h(linear(xg, g("g1"))), g("g2"))
     # F.normalize(p=2, dim=-1): x / max(||x||, 1e-12) with the norm rounded to f16 first (:632)
@@ -140,7 +149,7 @@ def tmix(layer_id, H, x, x_prev, v_first, S, z, att, elapsed_t):
     xo = group_norm_heads(y.reshape(B * T, C), H, g("ln_x.weight"), g("ln_x.bias")).reshape(B, T, C)   # :647
     bonus = ((r * k * g("r_k")).reshape(B, T, H, N).astype(F32).sum(axis=-1, keepdims=True, dtype=F32)).astype(F16)
     xo = xo + (bonus * v.reshape(B, T, H, N)).reshape(B, T, C)            # :648
-    return linear(xo * gate, g("output.weight")), v_first                 # :649
+    return proj(xo * gate, "output"), v_first                              # :649
 
 
 def cmix(x, x_prev, x_k, K_, V_):
@@ -190,7 +199,17 @@ def quantize_ffn(z, n_layer):
     return out
 
 
-def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None, mm8_blas=False):
+def quantize_att(z, n_layer):
+    """{layer: {"receptance" | "key" | "value" | "output": (q, mx, rx, my, ry)}} and the head's tuple: the time-mix projections and the
+    head as mm8 weights, each quantised in the orientation it multiplies with (w = W.T [N_in, M_out])."""
+    out = {}
+    for i in range(n_layer):
+        a = f"blocks.{i}.att."
+        out[i] = {n: quantize_weight(z[a + n + ".weight"].T) for n in ("receptance", "key", "value", "output")}
+    return out, quantize_weight(z["head.weight"].T)
+
+
+def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None, mm8_blas=False, att8=None, head8=None):
     """forward_seq_batch_seperate = _pre/_layers/_post, Albatross/rwkv7.py:503-563.
     tokens [B][T] ints (equal lengths); state = [s0 [L,2,B,C], s1 [L,B,H,64,64], s2 [B] int32],
     all numpy, updated IN PLACE.  Returns logits f16 [B,V] (or [B,T,V])."""
@@ -204,7 +223,7 @@ def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None, mm
     for i in range(n_layer):
         bbb, att, ffn = f"blocks.{i}.", f"blocks.{i}.att.", f"blocks.{i}.ffn."
         xx = layer_norm(x, z[bbb + "ln1.weight"], z[bbb + "ln1.bias"])
-        xx, v_first = tmix(i, H, xx, s0[i], v_first, s1[i], z, att, s2)
+        xx, v_first = tmix(i, H, xx, s0[i], v_first, s1[i], z, att, s2, att8=None if att8 is None else att8[i], mm8_blas=mm8_blas)
         x = x + xx
         xx = layer_norm(x, z[bbb + "ln2.weight"], z[bbb + "ln2.bias"])
         if mm8 is not None:
@@ -215,7 +234,11 @@ def forward_seq_batch(z, tokens, state, n_layer, full_output=False, mm8=None, mm
     if not full_output:
         x = x[:, -1, :]
     x = layer_norm(x, z["ln_out.weight"], z["ln_out.bias"])
-    logits = linear(x, z["head.weight"])
+    if head8 is not None:
+        mm = mm8_seq_blas if mm8_blas else native.mm8_seq
+        logits = mm(np.ascontiguousarray(x.reshape(-1, C)), *head8).reshape(x.shape[:-1] + (-1,))
+    else:
+        logits = linear(x, z["head.weight"])
     s2 += T                                                     # :552
     return logits
 
