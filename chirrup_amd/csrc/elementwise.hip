@@ -238,7 +238,11 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
             }
             continue;
         }
-        float ps0 = 0.f, ps1 = 0.f, ps2 = 0.f;
+        constexpr int NQ = NMIX >= 3 ? 3 : (NMIX == 1 ? 1 : 0);     // mix planes that can carry an mm8 prologue (r, k, v of six; the one of one)
+        const int n_q = p_xs ? (fz.out_planes > 0 ? (fz.out_planes < NQ ? fz.out_planes : NQ) : (NQ ? 1 : 0)) : 0;
+        float ps[NQ ? NQ : 1][3];
+#pragma unroll
+        for (int m = 0; m < (NQ ? NQ : 1); m++) ps[m][0] = ps[m][1] = ps[m][2] = 0.f;
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++) {
             const int c = threadIdx.x + q * kLnThreads;
@@ -258,25 +262,34 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
                     *reinterpret_cast<f16x8 *>(out + (int64_t)m * out_stride + ro + c * 8) = o;
-                    if (NMIX == 1 && p_xs) {  // mm8 activation prologue of the GEMM that consumes `out` (mm8_prep_kernel's arithmetic)
-                        const f16x8 rv = *reinterpret_cast<const f16x8 *>(p_ry + c * 8);
-                        const f16x8 yv = *reinterpret_cast<const f16x8 *>(p_my + c * 8);
+                    if (NQ > 0 && m < NQ && m < n_q) {  // mm8 activation prologue of the GEMM that consumes plane m (mm8_prep_kernel's arithmetic)
+                        const f16x8 rv = *reinterpret_cast<const f16x8 *>(p_ry + (int64_t)m * C + c * 8);
+                        const f16x8 yv = *reinterpret_cast<const f16x8 *>(p_my + (int64_t)m * C + c * 8);
                         f16x8 xs;
 #pragma unroll
                         for (int e = 0; e < 8; e++) {
                             xs[e] = (f16)((float)o[e] * (float)rv[e]);
-                            ps0 += (float)xs[e];
-                            ps1 += (float)o[e] * (float)yv[e];
-                            ps2 += (float)o[e];
+                            ps[m < NQ ? m : 0][0] += (float)xs[e];
+                            ps[m < NQ ? m : 0][1] += (float)o[e] * (float)yv[e];
+                            ps[m < NQ ? m : 0][2] += (float)o[e];
                         }
-                        *reinterpret_cast<f16x8 *>(p_xs + ro + c * 8) = xs;
+                        *reinterpret_cast<f16x8 *>(p_xs + (int64_t)m * out_stride + ro + c * 8) = xs;
                     }
                 }
             }
         }
-        if (NMIX == 1 && p_xs) {
-            block_sum3(ps0, ps1, ps2, red);
-            if (threadIdx.x == 0) fz.out_S[row * 3 + 0] = ps0, fz.out_S[row * 3 + 1] = ps1, fz.out_S[row * 3 + 2] = ps2;
+        if (NQ > 0) {
+            const int64_t rows_total = out_stride / C;                 // S of plane m: out_S[m][rows][3]
+#pragma unroll
+            for (int m = 0; m < NQ; m++) {
+                if (m < n_q) {                                         // (uniform over the workgroup)
+                    block_sum3(ps[m][0], ps[m][1], ps[m][2], red);
+                    if (threadIdx.x == 0) {
+                        float *dst = fz.out_S + ((int64_t)m * rows_total + row) * 3;
+                        dst[0] = ps[m][0], dst[1] = ps[m][1], dst[2] = ps[m][2];
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++)
@@ -428,7 +441,8 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
     if (fuse) q = *fuse;
     if (q.in_S && (!delta_partials || !q.in_rx || !q.in_mx)) return CHIRRUP_E_NULL;
     if (q.in_S && q.in_S_parts <= 0) q.in_S_parts = 1;
-    if (q.out_xs && (n_mix != 1 || !q.out_ry || !q.out_my || !q.out_S)) return q.out_xs && n_mix != 1 ? CHIRRUP_E_UNSUPPORTED : CHIRRUP_E_NULL;
+    if (q.out_xs && (n_mix == 0 || !q.out_ry || !q.out_my || !q.out_S)) return q.out_xs && n_mix == 0 ? CHIRRUP_E_UNSUPPORTED : CHIRRUP_E_NULL;
+    if (q.out_xs && (q.out_planes < 0 || q.out_planes > (n_mix == 1 ? 1 : 3))) return CHIRRUP_E_SHAPE;
     if (mis16(q.in_rx) || mis16(q.in_mx) || mis16(q.out_ry) || mis16(q.out_my) || mis16(q.out_xs)) return CHIRRUP_E_ALIGN;
     if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
     if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;

@@ -668,6 +668,8 @@ struct ChainTable {
     f16 *uY[4];                  // [M][up_ldy]
     int dN[4], dact[4], dfirst[5], uK[4];
     int n_lora, n_chain, dsplits, ld_hid, up_N, up_Kimg, up_ldy;
+    const f16 *m_rx[4], *m_mx[4];   // uint8 main problems (chain_gemm_kernel<.., true>): scales of problem b and the row sums [M][3] of
+    const float *m_S[4];            // its activation prologue -- the rank-1 corrections of the mm8 split form run in the tile's epilogue
     int halves;                  // 2: every tile as two workgroups over the two halves of the rows (M > 32); 1: whole rows
     int rkv_splits;              // halves == 1 only: K-slices of an R/K/V tile, reduced inside the launch by the last to arrive (EPI_PAIR)
     float *slab;                 // [down tile][half][slice][16 MT][128] binary32
@@ -682,9 +684,9 @@ constexpr int kChainWords = kChainTickets + kChainDone + 2 + kChainPairs;     //
 // ring is free again).  Loader waves come back too (ring_gemm_kernel's leave at this point).  D: ring slots.
 // chain_prologue: the loader waves' first D - 1 stages alone -- issued for the NEXT tile while the compute waves still store
 // the previous one (the up-projection share keeps its staging area apart from the ring), then chain_mainloop(.., true).
-template <int MT, int D>
-__device__ __forceinline__ void chain_stage(const Loader<false> &ld, const int kb, const int k_begin, const int n_base, unsigned char *smem) {
-    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * 128;
+template <int MT, int D, bool W8 = false>
+__device__ __forceinline__ void chain_stage(const Loader<W8> &ld, const int kb, const int k_begin, const int n_base, unsigned char *smem) {
+    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * (W8 ? 64 : 128);
     constexpr int kXRounds = (MT + 1) / 2, kWLoads = kWBytes / 16 / 256;
     const int lw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3;
     const bool short_x = (MT & 1) && lw >= 2;
@@ -708,11 +710,11 @@ __device__ __forceinline__ void chain_prologue(const Tile &t, const int ldx, con
         if (p < nkb) chain_stage<MT, D>(ld, p, k_begin, n_base, smem);
 }
 
-template <int MT, int D>
+template <int MT, int D, bool W8 = false>
 __device__ __forceinline__ void chain_mainloop(const Tile &t, const int ldx, const int64_t ldw, const int K_img, const int k_begin,
                                                const int nkb, const int n_base, unsigned char *smem, f32x4 (&acc)[2][MT],
                                                const bool prologue_issued = false) {
-    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * 128;
+    constexpr int kXBytes = MT * 16 * 128, kWBytes = 128 * (W8 ? 64 : 128);
     constexpr int kXRounds = (MT + 1) / 2, kWLoads = kWBytes / 16 / 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -725,11 +727,11 @@ __device__ __forceinline__ void chain_mainloop(const Tile &t, const int ldx, con
     for (int nt = 0; nt < 2; nt++)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const Loader<false> ld(t, t.M, ldx, ldw, K_img, lt);
+    const Loader<W8> ld(t, t.M, ldx, ldw, K_img, lt);
     if (!computes && !prologue_issued) {
 #pragma unroll
         for (int p = 0; p < D - 1; p++)
-            if (p < nkb) chain_stage<MT, D>(ld, p, k_begin, n_base, smem);
+            if (p < nkb) chain_stage<MT, D, W8>(ld, p, k_begin, n_base, smem);
     }
     for (int kb = 0; kb < nkb; kb++) {
         if (!computes) {
@@ -739,10 +741,10 @@ __device__ __forceinline__ void chain_mainloop(const Tile &t, const int ldx, con
         }
         asm volatile("s_barrier" ::: "memory");
         if (!computes) {
-            if (kb + D - 1 < nkb) chain_stage<MT, D>(ld, kb + D - 1, k_begin, n_base, smem);
+            if (kb + D - 1 < nkb) chain_stage<MT, D, W8>(ld, kb + D - 1, k_begin, n_base, smem);
         } else {
             f16x8 wf[2][2];
-            read_w_frags<false>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
+            read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
             mma_kblock<MT>(xring + (kb % D) * kXBytes, wf, c, q, acc, [] {});
         }
     }
@@ -766,7 +768,7 @@ __device__ __forceinline__ bool chain_wait(int *word, const int want, const int 
     return false;
 }
 
-template <int MT>
+template <int MT, bool W8M = false>
 __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int K, const int ldx, const int64_t ldw,
                                                          const GroupTable gt, const ChainTable ct) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -804,12 +806,16 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
         t.bias = gt.bias[b], t.part = gt.part[b], t.Np = gt.N[b], t.ldy = gt.ldy[b], t.act = gt.act[b], t.w_tiled = gt.tiled[b] != 0;
         const int n_base = t.ngroup * 128, k_slice = K / ct.rkv_splits;
         if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8] = __builtin_amdgcn_s_memrealtime();
-        chain_mainloop<MT, ring_depth<MT, false>()>(t, ldx, ldw, K, kslice * k_slice, k_slice / kKB, n_base, smem, acc);
+        chain_mainloop<MT, ring_depth<MT, W8M>(), W8M>(t, ldx, ldw, K, kslice * k_slice, k_slice / kKB, n_base, smem, acc);
         if (ct.stamps && tid == 0) ct.stamps[(int64_t)L * 8 + 1] = __builtin_amdgcn_s_memrealtime();
         if (!computes) return;
         if (n_base + wave * 32 < t.Np) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
         __syncthreads();                               // (the four compute waves; finished waves do not count)
-        if (ct.rkv_splits > 1) {                       // ring_gemm_kernel's EPI_PAIR epilogue (same hand-off, same bits as a reduce launch)
+        if constexpr (W8M) {                           // uint8 weights: y = rx*(core - 1023.5*S0) + S1 + mx*S2 (ring_gemm_kernel's EPI_MM8)
+            Mm8Epilogue e8{};
+            e8.rx = ct.m_rx[b], e8.mx = ct.m_mx[b], e8.S = ct.m_S[b], e8.S_parts = 1;
+            store_staged_mm8<256>(stg, t.M, n_base, t, e8);
+        } else if (ct.rkv_splits > 1) {                       // ring_gemm_kernel's EPI_PAIR epilogue (same hand-off, same bits as a reduce launch)
             int *const pair = ct.sync + kChainTickets + kChainDone + 2 + t.pair_id;
             store_staged_sc1<256>(stg, t.M, n_base, t, t.kslice);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1747,30 +1753,25 @@ extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, co
     return b + 256;
 }
 
-extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
-                                const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
-                                void *workspace, void *sync, int spin_limit, void *stream) {
-    if (n_main <= 0 || n_main > 4 || n_lora <= 0 || n_lora > 4 || !main_p || !lora) return CHIRRUP_E_SHAPE;
-    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & 7)) return CHIRRUP_E_SHAPE;
+namespace {
+// the launch behind rwkv7_tmix_gemms (binary16 main problems in gt) and rwkv7_tmix_gemms_mm8 (uint8: w8 = true, scales / row sums in m_*)
+int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, const f16 *const *m_rx, const f16 *const *m_mx,
+                const float *const *m_S, int n_lora, const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy,
+                int row_halves, void *workspace, void *sync, int spin_limit, void *stream) {
+    const int n_main = gt.used;
+    if (n_lora <= 0 || n_lora > 4 || !lora) return CHIRRUP_E_SHAPE;
+    if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & (w8 ? 15 : 7))) return CHIRRUP_E_SHAPE;
     if (up_n <= 0 || (up_n % kTileRows) || up_kimg <= 0 || (up_kimg % kKB) || up_ldy < up_n || (up_ldy & 3) || ld_hid < up_kimg || (ld_hid & 7))
         return CHIRRUP_E_SHAPE;
     if (!workspace || !sync) return CHIRRUP_E_NULL;
     if (mis16(workspace) || (reinterpret_cast<uintptr_t>(sync) & 15)) return CHIRRUP_E_ALIGN;
-    GroupTable gt{};
-    gt.used = n_main;
-    for (int i = 0; i < n_main; i++) {
-        const chirrup_gemm_problem &q = main_p[i];
-        if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
-        if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
-        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7) || (reinterpret_cast<uintptr_t>(q.bias) & 7)) return CHIRRUP_E_ALIGN;
-        if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
-        gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y), gt.bias[i] = static_cast<const f16 *>(q.bias);
-        gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act, gt.tiled[i] = q.w_tiled ? 1 : 0;
-        gt.first[i + 1] = gt.first[i] + (q.n + kTileRows - 1) / kTileRows;
-    }
     ChainTable ct{};
     ct.n_lora = n_lora, ct.dsplits = chain_dsplits(K), ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
     chain_plan(M, K, gt.first[n_main], row_halves, ct.halves, ct.rkv_splits);
+    if (w8) {
+        ct.rkv_splits = 1;                             // (the corrections run in the tile's own epilogue: unsplit tiles only)
+        for (int i = 0; i < n_main; i++) ct.m_rx[i] = m_rx[i], ct.m_mx[i] = m_mx[i], ct.m_S[i] = m_S[i];
+    }
     for (int p = 0; p < n_lora; p++) {
         const chirrup_lora_problem &q = lora[p];
         if (q.n <= 0 || (q.n % kKB) || q.n > ld_hid || q.k_up <= 0 || (q.k_up % kKB) || q.k_up > q.n || q.k_up > up_kimg || q.act < 0 || q.act > 3)
@@ -1803,11 +1804,11 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
     ct.spin_limit = spin_limit > 0 ? spin_limit : 400000;          // x ~0.25 us of s_sleep: ~0.1 s
     const dim3 grid(ct.n_chain + main_wgs);
     ct.stamps = (g_clock_probe && g_clock_pairs >= (int)grid.x * 4) ? g_clock_probe : nullptr;
-    const size_t lds = lds_bytes(128, MT, false);
+    const size_t lds = lds_bytes(128, MT, false);       // (>= the uint8 main tiles' ring: the chain workgroups stream binary16 weights)
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define CHAIN_GO(MTV)                                                                                                          \
+#define CHAIN_GO_K(MTV, W8V)                                                                                                   \
     do {                                                                                                                       \
-        auto kern = chain_gemm_kernel<MTV>;                                                                                    \
+        auto kern = chain_gemm_kernel<MTV, W8V>;                                                                               \
         static std::atomic<bool> lds_limit_raised[32];                                                                         \
         int dev_ = 0;                                                                                                          \
         (void)hipGetDevice(&dev_);                                                                                             \
@@ -1816,6 +1817,11 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
             lds_limit_raised[dev_ & 31].store(true, std::memory_order_release);                                                \
         }                                                                                                                      \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, K, ldx, ldw, gt, ct);                                            \
+    } while (0)
+#define CHAIN_GO(MTV)                     \
+    do {                                  \
+        if (w8) CHAIN_GO_K(MTV, true);    \
+        else CHAIN_GO_K(MTV, false);      \
     } while (0)
     switch (MT) {
         case 1: CHAIN_GO(1); break;
@@ -1829,7 +1835,57 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
         default: return CHIRRUP_E_UNSUPPORTED;         // whole rows above 128: not used (row halves from 128 rows on)
     }
 #undef CHAIN_GO
+#undef CHAIN_GO_K
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
+                                const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
+                                void *workspace, void *sync, int spin_limit, void *stream) {
+    if (n_main <= 0 || n_main > 4 || !main_p) return CHIRRUP_E_SHAPE;
+    GroupTable gt{};
+    gt.used = n_main;
+    for (int i = 0; i < n_main; i++) {
+        const chirrup_gemm_problem &q = main_p[i];
+        if (q.n <= 0 || (q.n & 3) || q.ldy < q.n || (q.ldy & 3) || q.act < 0 || q.act > 3) return CHIRRUP_E_SHAPE;
+        if (!q.x || !q.w || !q.y) return CHIRRUP_E_NULL;
+        if (mis16(q.x) || mis16(q.w) || (reinterpret_cast<uintptr_t>(q.y) & 7) || (reinterpret_cast<uintptr_t>(q.bias) & 7)) return CHIRRUP_E_ALIGN;
+        if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+        gt.X[i] = static_cast<const f16 *>(q.x), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y), gt.bias[i] = static_cast<const f16 *>(q.bias);
+        gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = q.act, gt.tiled[i] = q.w_tiled ? 1 : 0;
+        gt.first[i + 1] = gt.first[i] + (q.n + kTileRows - 1) / kTileRows;
+    }
+    return tmix_launch(false, M, K, ldx, ldw, gt, nullptr, nullptr, nullptr, n_lora, lora, ld_hid, up_n, up_kimg, up_ldy, row_halves, workspace,
+                       sync, spin_limit, stream);
+}
+
+// The same launch with uint8 (mm8, w8a16) main problems: y = mm8(x, w) in the reference's split form -- xs = the activation
+// prologue binary16(x * ry) [M][ldx], S [M][3] its row sums {sum xs, sum x*my, sum x} (both written by rwkv7_add_ln_mix_mm8 with
+// out_planes = 3), wT the K-contiguous uint8 weights [n][K] (tile images of skinny_tile_weight_u8 when w_tiled, else row stride
+// ldw), rx / mx [n] the column scales; the rank-1 corrections run in each tile's epilogue (as mm8t_gemm_fused).  n % 8 == 0,
+// ldy % 8 == 0, 16-byte aligned y / rx / mx.  The LoRA problems stay binary16.
+extern "C" int rwkv7_tmix_gemms_mm8(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_mm8_problem *main_p, int n_lora,
+                                    const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
+                                    void *workspace, void *sync, int spin_limit, void *stream) {
+    if (n_main <= 0 || n_main > 4 || !main_p) return CHIRRUP_E_SHAPE;
+    GroupTable gt{};
+    gt.used = n_main;
+    const f16 *rx[4], *mx[4];
+    const float *S[4];
+    for (int i = 0; i < n_main; i++) {
+        const chirrup_mm8_problem &q = main_p[i];
+        if (q.n <= 0 || (q.n & 7) || q.ldy < q.n || (q.ldy & 7)) return CHIRRUP_E_SHAPE;
+        if (!q.xs || !q.w || !q.y || !q.rx || !q.mx || !q.S) return CHIRRUP_E_NULL;
+        if (mis16(q.xs) || mis16(q.w) || mis16(q.y) || mis16(q.rx) || mis16(q.mx)) return CHIRRUP_E_ALIGN;
+        if (q.w_tiled && (q.n % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+        gt.X[i] = static_cast<const f16 *>(q.xs), gt.W[i] = q.w, gt.Y[i] = static_cast<f16 *>(q.y), gt.bias[i] = nullptr;
+        gt.N[i] = q.n, gt.ldy[i] = q.ldy, gt.act[i] = 0, gt.tiled[i] = q.w_tiled ? 1 : 0;
+        gt.first[i + 1] = gt.first[i] + (q.n + kTileRows - 1) / kTileRows;
+        rx[i] = static_cast<const f16 *>(q.rx), mx[i] = static_cast<const f16 *>(q.mx), S[i] = q.S;
+    }
+    return tmix_launch(true, M, K, ldx, ldw, gt, rx, mx, S, n_lora, lora, ld_hid, up_n, up_kimg, up_ldy, row_halves, workspace, sync,
+                       spin_limit, stream);
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,

@@ -65,6 +65,7 @@ SIGNATURES = {
     "rwkv7_tmix_sync_words": (_i, []),
     "rwkv7_tmix_status_word": (_i, []),
     "rwkv7_tmix_gemms_workspace_bytes": (_i64, [_i, _i, _i, _vp, _i, _vp, _i]),
+    "rwkv7_tmix_gemms_mm8": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "skinny_gemm_clock_probe": (_i, [_vp, _i]),
     "chirrup_clock_probe": (_i, [_i, _vp, _vp]),

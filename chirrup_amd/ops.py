@@ -290,7 +290,8 @@ def _chk16(name, t, numel=None):
 class _Mm8Fuse(ctypes.Structure):
     """chirrup_mm8_fuse of include/chirrup_amd.h"""
     _fields_ = [("in_rx", ctypes.c_void_p), ("in_mx", ctypes.c_void_p), ("in_S", ctypes.c_void_p), ("out_ry", ctypes.c_void_p),
-                ("out_my", ctypes.c_void_p), ("out_xs", ctypes.c_void_p), ("out_S", ctypes.c_void_p), ("in_S_parts", ctypes.c_int)]
+                ("out_my", ctypes.c_void_p), ("out_xs", ctypes.c_void_p), ("out_S", ctypes.c_void_p), ("in_S_parts", ctypes.c_int),
+                ("out_planes", ctypes.c_int)]
 
 
 def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, prev_in, prev_out, mix, out,
@@ -298,7 +299,8 @@ def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, 
     """x_new = x (+delta) -> x_out; cur = LN(x_new); out[m] = cur + (shifted - cur) * mix[m]
     (mix [n,C], out [n,B,T,C], n in {1,6}) or out = cur when mix is None.  See include/chirrup_amd.h.
     mm8_in = (rx [C], mx [C], S fp32 [B*T,3] or [B*T,parts,3]): delta_partials are the core sums of an mm8 product, corrected here;
-    mm8_out = (ry [C], my [C], xs fp16 [B*T,C], S fp32 [B*T,3]): also write the mm8 prologue of out (n_mix == 1)."""
+    mm8_out = (ry [C], my [C], xs fp16 [B*T,C], S fp32 [B*T,3]): also write the mm8 prologue of out (n_mix == 1); with six mix
+    planes (ry, my [3,C], xs [3,B*T,C], S [3,B*T,3]): the prologues of planes 0..2 (the uint8 R/K/V products)."""
     n_mix = 0 if mix is None else mix.shape[0]
     for name, t in (("x", x), ("delta", delta), ("x_out", x_out)):
         _chk16(name, t, B * T * C)
@@ -331,9 +333,10 @@ def add_ln_mix(B: int, T: int, C: int, x, delta, x_out, ln_w, ln_b, eps: float, 
             fz.in_rx, fz.in_mx, fz.in_S, fz.in_S_parts = rx.data_ptr(), mx.data_ptr(), S.data_ptr(), S.numel() // (B * T * 3)
         if mm8_out is not None:
             ry, my, xs, S = mm8_out
-            _chk16("mm8_out ry", ry, C), _chk16("mm8_out my", my, C), _chk16("mm8_out xs", xs, B * T * C)
-            _chk(S, "mm8_out S", torch.float32, (B * T, 3))
-            fz.out_ry, fz.out_my, fz.out_xs, fz.out_S = ry.data_ptr(), my.data_ptr(), xs.data_ptr(), S.data_ptr()
+            planes = ry.numel() // C                  # 1, or (six mix planes) 2..3: the prologues of r, k, v
+            _chk16("mm8_out ry", ry, planes * C), _chk16("mm8_out my", my, planes * C), _chk16("mm8_out xs", xs, planes * B * T * C)
+            _chk(S, "mm8_out S", torch.float32, (B * T, 3) if planes == 1 else (planes, B * T, 3))
+            fz.out_ry, fz.out_my, fz.out_xs, fz.out_S, fz.out_planes = ry.data_ptr(), my.data_ptr(), xs.data_ptr(), S.data_ptr(), planes
         fuse = ctypes.addressof(fz)
     rc = _lib.load().rwkv7_add_ln_mix_mm8(B, T, C, n_mix, _ptr(x), _ptr(delta), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps,
                                           _ptr(prev_in), _ptr(prev_out), _ptr(mix), _ptr(out), B * T * C, _ptr(slot_idx),
@@ -637,17 +640,38 @@ def chain_status() -> int:
     return int(sum(int(t[i]) for t in _chain_sync.values()))
 
 
-def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, row_halves: bool = True, spin_limit: int = 0) -> None:
+class _Mm8Problem(ctypes.Structure):
+    """chirrup_mm8_problem of include/chirrup_amd.h"""
+    _fields_ = [("xs", ctypes.c_void_p), ("w", ctypes.c_void_p), ("y", ctypes.c_void_p), ("rx", ctypes.c_void_p), ("mx", ctypes.c_void_p),
+                ("S", ctypes.c_void_p), ("n", ctypes.c_int), ("ldy", ctypes.c_int), ("w_tiled", ctypes.c_int)]
+
+
+def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, row_halves: bool = True, spin_limit: int = 0,
+               mm8: bool = False) -> None:
     """R/K/V and the whole LoRA chain of a layer in ONE launch (include/chirrup_amd.h: rwkv7_tmix_gemms).
-    main: list of (x [M,K], weight [N,K] or TiledWeight, out [M,N]);
+    main: list of (x [M,K], weight [N,K] or TiledWeight, out [M,N]); with mm8=True (uint8 R/K/V: rwkv7_tmix_gemms_mm8) a list of
+          (xs [M,K] fp16 prologue, (qT uint8 tile images or [N,K], tiled), out [M,N], rx [N], mx [N], S fp32 [M,3]);
     lora: list of (x [M,K], w_down [n,K] row-major, plane index z into hid / up_weight, bias [C] or None, out [M,C], act, k_up);
     hid [Z, M, ld_hid] fp16 scratch; up_weight: tile images of [Z, C, ld_hid]."""
     x0 = main[0][0]
     M, K = x0.shape
     L = _lib.load()
     marr = (_GemmProblem * len(main))()
+    qarr = (_Mm8Problem * len(main))()
     ldw = None
-    for i, (x, w, out) in enumerate(main):
+    if mm8:
+        for i, (xs, (qT, q_tiled), out, rx, mx, S) in enumerate(main):
+            N = out.shape[1]
+            if tuple(xs.shape) != (M, K) or xs.stride(0) != x0.stride(0) or xs.dtype != torch.float16 or tuple(out.shape) != (M, N):
+                raise _lib.ChirrupAmdError("tmix_gemms: problems must share M, K and the row stride of xs")
+            if qT.dtype != torch.uint8 or qT.numel() != N * K or not qT.is_cuda:
+                raise _lib.ChirrupAmdError("tmix_gemms: qT must hold N*K uint8 weights")
+            _chk16("rx", rx, N), _chk16("mx", mx, N)
+            _chk(S, "S", torch.float32, (M, 3))
+            qarr[i] = _Mm8Problem(xs.data_ptr(), qT.data_ptr(), out.data_ptr(), rx.data_ptr(), mx.data_ptr(), S.data_ptr(), N, out.stride(0),
+                                  int(q_tiled))
+            marr[i] = _GemmProblem(xs.data_ptr(), qT.data_ptr(), out.data_ptr(), None, N, out.stride(0), 0, int(q_tiled))    # (sizing only)
+    for i, (x, w, out) in enumerate(main if not mm8 else []):
         N, wptr, ldw_i, w_tiled = _weight_args(w, K)
         if not w_tiled:
             ldw = ldw_i if ldw is None else ldw
@@ -679,9 +703,9 @@ def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, row
     nbytes = L.rwkv7_tmix_gemms_workspace_bytes(M, K, len(main), ctypes.addressof(marr), len(lora), ctypes.addressof(larr), int(row_halves))
     ws, sync = _chain_state(x0.device, nbytes + 256)
     base = (ws.data_ptr() + 255) // 256 * 256
-    rc = L.rwkv7_tmix_gemms(M, K, x0.stride(0), ldw if ldw is not None else K, len(main), ctypes.addressof(marr), len(lora),
-                            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, int(row_halves), base, sync.data_ptr(), spin_limit,
-                            _stream())
+    fn, arr = (L.rwkv7_tmix_gemms_mm8, qarr) if mm8 else (L.rwkv7_tmix_gemms, marr)
+    rc = fn(M, K, x0.stride(0), ldw if ldw is not None else K, len(main), ctypes.addressof(arr), len(lora),
+            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, int(row_halves), base, sync.data_ptr(), spin_limit, _stream())
     if rc != 0:
         try:
             sync.zero_()

@@ -580,6 +580,7 @@ class RWKV_x070:
         a8 = self.att_dtype == torch.int8
         a8_out_fused = a8 and hw and T == 1 and fuse_core and self.skinny_att_out
         S_o = torch.empty((rows, H, 3), dtype=torch.float32, device=dev) if a8_out_fused else None
+        xs_rkv = S_rkv = None
         if q8:
             f32 = dict(dtype=torch.float32, device=dev)
             xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
@@ -605,8 +606,16 @@ class RWKV_x070:
             # residual add of the previous channel-mix + LN1 + token shift + six lerps
             prev = s0[i][0]
             upd = delta is not None or dparts is not None
+            # uint8 R/K/V in the decode regime: LN1 also writes their three activation prologues, the time-mix launch multiplies
+            # them against the uint8 tiles and corrects in the tiles' epilogues (rwkv7_tmix_gemms_mm8)
+            a8_rkv_fused = (a8 and hw and T == 1 and self.group_tmix_gemms and self.chain_tmix_gemms and lw.a8_tiled
+                            and lw.lora2_t is not None and (rh["rkv"] or rows <= 128))
+            if a8_rkv_fused and xs_rkv is None:
+                xs_rkv = new(3, rows, C)
+                S_rkv = torch.empty((3, rows, 3), dtype=torch.float32, device=dev)
             ops.add_ln_mix(B, T, C, x, delta, (x if T == 1 else x_alt) if upd else None, lw.ln1_w, lw.ln1_b,
-                           1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts, mm8_in=dq)
+                           1e-5, prev, prev if T == 1 else carry, lw.mix6, mixed, slot_idx, delta_partials=dparts, mm8_in=dq,
+                           mm8_out=(lw.rkv8_ry, lw.rkv8_my, xs_rkv, S_rkv) if a8_rkv_fused else None)
             if T > 1:
                 if upd:
                     x, x_alt = x_alt, x
@@ -618,11 +627,20 @@ class RWKV_x070:
             grouped = hw and self.group_tmix_gemms
             chained = (grouped and self.chain_tmix_gemms and ops.TMIX_CHAIN and rows >= self.chain_min_rows and (rh["rkv"] or rows <= 128)
                        and lw.lora2_t is not None and lw.rkv_t is not None and not gs["rkv"] and not a8)
-            if a8:                                             # r, k, v through the uint8 weights
+            if a8 and not a8_rkv_fused:                        # r, k, v through the uint8 weights, one product at a time
                 rkv = new(3, rows, C)
                 for j, w8 in enumerate((lw.R8, lw.K8, lw.V8)):
                     ops.mm8t_linear(mixed[j], *w8, out=rkv[j], tiled=lw.a8_tiled)
-            if chained:
+            if a8_rkv_fused:
+                rkv = new(3, rows, C)
+                hid = new(4 - p0, rows, lw.lora1.shape[1])
+                up = new(4 - p0, rows, C)
+                main_p = [(xs_rkv[j], (w8.qT, True), rkv[j], w8.rx, w8.mx, S_rkv[j]) for j, w8 in enumerate((lw.R8, lw.K8, lw.V8))]
+                lora_p = [(mixed[2 + j], lw.lora1[j, :lw.lora_k[j]], j - p0, lw.lbias[j].view(-1), up[j - p0],
+                           ("tanh" if j == 1 else ("sigmoid" if j == 3 else None)), lw.lora_k[j]) for j in range(p0, 4)]
+                ops.tmix_gemms(main_p, lora_p, lw.lora2_t[p0:], hid, row_halves=rh["rkv"], mm8=True)
+                side = None
+            elif chained:
                 # ONE launch for R/K/V AND the whole LoRA chain: down-projections, activations and up-projections run on the CUs
                 # the R/K/V tiles leave idle, beside them (chain_gemm_kernel) -- no second launch for the up-projections
                 rkv = new(3, rows, C)

@@ -159,6 +159,9 @@ typedef struct {
     void *out_xs;                /* binary16 [B][T][C] */
     float *out_S;                /* [B*T][3] */
     int in_S_parts;              /* 0 or 1: one sum per row; mm8_reduce_rows writes mm8_row_parts(C) of them, mm8t_gemm_fused mm8_tile_parts(C) */
+    int out_planes;              /* 0 or 1: the prologue of mix plane 0 (n_mix = 1, or 6); 2..3 (n_mix = 6): of planes 0..out_planes-1
+                                    (r, k, v) -- out_ry / out_my then [out_planes][C], out_xs [out_planes][B*T][C] (plane stride =
+                                    out_stride), out_S [out_planes][B*T][3] */
 } chirrup_mm8_fuse;
 int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                          const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
@@ -319,6 +322,18 @@ typedef struct {
     void *y;            /* [M][up_ldy] binary16 */
     int n, k_up, act;
 } chirrup_lora_problem;
+/* A uint8 (mm8, w8a16) main problem of rwkv7_tmix_gemms_mm8: y = mm8(x, w) in the split form of scripts/test_mm8/benchmark.py:
+ * 167-179 -- xs [M][ldx] = binary16(x * ry) and S [M][3] = {sum xs, sum x*my, sum x} are the product's activation prologue
+ * (rwkv7_add_ln_mix_mm8 writes them for r, k, v with out_planes = 3), w the K-contiguous uint8 weights [n][K] (tile images of
+ * skinny_tile_weight_u8 when w_tiled), rx / mx [n] the column scales.  n % 8 == 0, ldy % 8 == 0, 16-byte aligned y / rx / mx. */
+typedef struct {
+    const void *xs;
+    const void *w;
+    void *y;
+    const void *rx, *mx;
+    const float *S;
+    int n, ldy, w_tiled;
+} chirrup_mm8_problem;
 int rwkv7_tmix_sync_words(void);
 int rwkv7_tmix_status_word(void);
 int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
@@ -326,6 +341,11 @@ int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, const chirrup
 int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
                      const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves, void *workspace,
                      void *sync, int spin_limit, void *stream);
+/* ... with uint8 main problems (R/K/V as mm8 weights; the rank-1 corrections run in each tile's epilogue); the LoRA problems,
+ * workspace (size it with the binary16 call's function, passing n and w_tiled of the uint8 problems) and sync as above. */
+int rwkv7_tmix_gemms_mm8(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_mm8_problem *main_problems, int n_lora,
+                         const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
+                         void *workspace, void *sync, int spin_limit, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight
