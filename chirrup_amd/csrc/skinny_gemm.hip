@@ -513,6 +513,45 @@ __device__ __forceinline__ void combine_store(const float *stage, const int M, c
     }
 }
 
+// ... for a uint8 (mm8) product: the slices' sums are core sums sum_k xs*(1024 + q); the last arriver applies the rank-1
+// corrections y = rx*(core - 1023.5*S0) + S1 + mx*S2 (store_staged_mm8's arithmetic; S [M][3], one part per row)
+template <int THREADS>
+__device__ __forceinline__ void combine_store_mm8(const float *stage, const int M, const int n_first, const Tile &t, const int own_slice,
+                                                  const int slices, const f16 *rx, const f16 *mx, const float *S) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31;
+    const int n = n_first + 4 * c4;
+    if (n >= t.Np) return;
+    constexpr int RP = THREADS / 32;
+    const __amdgpu_buffer_rsrc_t src = make_rsrc(t.part, (int64_t)slices * M * t.Np * 4);
+    const f16x4 rxv = *reinterpret_cast<const f16x4 *>(rx + n), mxv = *reinterpret_cast<const f16x4 *>(mx + n);
+    for (int m0 = tid >> 5; m0 < M; m0 += RP * 2) {
+        f32x4 oth[2][kPairMaxSlices];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices && k != own_slice)
+                    oth[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((k * M + m0 + u * RP) * t.Np + n) * 4, 0, 16));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int m = m0 + u * RP;
+            if (m >= M) break;
+            const f32x4 own = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 4 * c4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices) v += (k == own_slice) ? own : oth[u][k];
+            const float *sp = S + (int64_t)(t.rows0 + m) * 3;
+            const float s0 = sp[0], s1 = sp[1], s2 = sp[2];
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (f16)((float)rxv[e] * (v[e] - (kU8Offset - 0.5f) * s0) + s1 + (float)mxv[e] * s2);
+            *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
+        }
+    }
+}
+
 // accumulators of the wave that owns staged columns col0 .. col0+31: acc[nt][mt][i] is m = 16 mt + c, n = col0 + 16 nt + 4q + i
 template <int MT>
 __device__ __forceinline__ void stage_acc(float *stage, const f32x4 (&acc)[2][MT], const int M, const int col0, const int c, const int q) {
@@ -811,7 +850,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
         if (!computes) return;
         if (n_base + wave * 32 < t.Np) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
         __syncthreads();                               // (the four compute waves; finished waves do not count)
-        if constexpr (W8M) {                           // uint8 weights: y = rx*(core - 1023.5*S0) + S1 + mx*S2 (ring_gemm_kernel's EPI_MM8)
+        if (W8M && ct.rkv_splits == 1) {               // uint8 weights: y = rx*(core - 1023.5*S0) + S1 + mx*S2 (ring_gemm_kernel's EPI_MM8)
             Mm8Epilogue e8{};
             e8.rx = ct.m_rx[b], e8.mx = ct.m_mx[b], e8.S = ct.m_S[b], e8.S_parts = 1;
             store_staged_mm8<256>(stg, t.M, n_base, t, e8);
@@ -827,7 +866,10 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
             }
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (*flag) combine_store<256>(stg, t.M, n_base, t, t.kslice, ct.rkv_splits);
+            if (*flag) {
+                if (W8M) combine_store_mm8<256>(stg, t.M, n_base, t, t.kslice, ct.rkv_splits, ct.m_rx[b], ct.m_mx[b], ct.m_S[b]);
+                else combine_store<256>(stg, t.M, n_base, t, t.kslice, ct.rkv_splits);
+            }
         } else {
             store_staged<EPI_F16, 256>(stg, t.M, n_base, t, 0, M);
         }
@@ -1769,7 +1811,6 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
     ct.n_lora = n_lora, ct.dsplits = chain_dsplits(K), ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
     chain_plan(M, K, gt.first[n_main], row_halves, ct.halves, ct.rkv_splits);
     if (w8) {
-        ct.rkv_splits = 1;                             // (the corrections run in the tile's own epilogue: unsplit tiles only)
         for (int i = 0; i < n_main; i++) ct.m_rx[i] = m_rx[i], ct.m_mx[i] = m_mx[i], ct.m_S[i] = m_S[i];
     }
     for (int p = 0; p < n_lora; p++) {

@@ -515,3 +515,56 @@ def test_time_mix_launch_with_the_lora_chain_inside(M, C, ranks, p0, halves):
             assert not bool(torch.isnan(up[z]).any()), (it, j)
             assert bool(((up[z].double() - ref_up[z]).abs() <= 4e-3 * ref_up[z].abs().clamp_min(1.0)).all()), (it, j)
             assert float((up[z].float() - want_up[z].float()).abs().max()) <= 8e-3 * max(1.0, float(want_up[z].abs().max()))
+
+
+@pytest.mark.parametrize("M,C,halves", [(200, 2048, True), (64, 2048, False), (64, 1024, True), (32, 2048, False), (17, 1024, False), (1, 768, False)])
+def test_time_mix_launch_with_uint8_main_tiles(M, C, halves):
+    """rwkv7_tmix_gemms_mm8: R/K/V as uint8 (mm8) tiles inside the time-mix launch -- activation prologues xs = fp16(x * ry) and row
+    sums given, the rank-1 corrections in the tiles' epilogues (unsplit tiles) or after the in-launch reduction (<= 64 rows:
+    split over K).  Against mm8t_linear per problem (the same split form: same xs, same uint8 bytes; only the binary32 order
+    of the K split differs) and, for the LoRA chain, against binary64.  NaN-poisoned outputs, 10 launches."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(M + C)
+    K, ranks = C, [64, 128, 64, 128]
+    dmax = 128
+    x = torch.randn(3, M, K, device="cuda").half()
+    mixed = torch.randn(6, M, K, device="cuda").half()
+    q8 = []
+    for j in range(3):
+        qT = torch.randint(0, 256, (C, K), device="cuda", dtype=torch.uint8)
+        rx, mx = torch.rand(C, device="cuda").half() / 64, torch.randn(C, device="cuda").half() * 0.01
+        my, ry = torch.randn(K, device="cuda").half() * 0.01, torch.rand(K, device="cuda").half() / 16
+        q8.append((qT, ops.tile_weight_u8(qT), mx, rx, my, ry))
+    xs = torch.stack([(x[j].float() * q8[j][5].float()).half() for j in range(3)])
+    S = torch.stack([torch.stack([xs[j].float().sum(1), (x[j].float() * q8[j][4].float()).sum(1), x[j].float().sum(1)], 1) for j in range(3)]).contiguous()
+    want = [ops.mm8t_linear(x[j], q8[j][1], q8[j][2], q8[j][3], q8[j][4], q8[j][5], tiled=True) for j in range(3)]
+    lora1 = torch.zeros(4, dmax, K, device="cuda", dtype=torch.float16)
+    lora2 = torch.zeros(4, C, dmax, device="cuda", dtype=torch.float16)
+    for j, r in enumerate(ranks):
+        lora1[j, :r] = (torch.randn(r, K, device="cuda") / K ** 0.5).half()
+        lora2[j, :, :r] = (torch.randn(C, r, device="cuda") / r ** 0.5).half()
+    lora2_t = ops.tile_weight_batch(lora2)
+    lbias = torch.randn(4, 1, C, device="cuda").half()
+    acts = [None, "tanh", None, "sigmoid"]
+    rkv = torch.empty(3, M, C, device="cuda", dtype=torch.float16)
+    hid = torch.empty(4, M, dmax, device="cuda", dtype=torch.float16)
+    up = torch.empty(4, M, C, device="cuda", dtype=torch.float16)
+    main_p = [(xs[j], (q8[j][1], True), rkv[j], q8[j][3], q8[j][2], S[j]) for j in range(3)]
+    lora_p = [(mixed[2 + j], lora1[j, :ranks[j]], j, lbias[j].view(-1), up[j], acts[j], ranks[j]) for j in range(4)]
+    ref_up = []
+    for j in range(4):
+        h = (mixed[2 + j].double() @ lora1[j, :ranks[j]].double().t()).half().double()
+        h = torch.tanh(h) if acts[j] == "tanh" else (torch.sigmoid(h) if acts[j] == "sigmoid" else h)
+        ref_up.append(h.half().double() @ lora2[j, :, :ranks[j]].double().t() + lbias[j].double())
+    for it in range(10):
+        rkv.fill_(float("nan")), hid.fill_(float("nan")), up.fill_(float("nan"))
+        ops.tmix_gemms(main_p, lora_p, lora2_t, hid, row_halves=halves, mm8=True)
+        torch.cuda.synchronize()
+        assert ops.chain_status() == 0 and all(int(t.abs().sum()) == 0 for t in ops._chain_sync.values())
+        for j in range(3):
+            assert not bool(torch.isnan(rkv[j]).any()), (it, j)
+            scale = float(want[j].float().abs().max())
+            assert float((rkv[j].float() - want[j].float()).abs().max()) <= 2e-3 * max(1.0, scale), (it, j)
+        for j in range(4):
+            assert bool(((up[j].double() - ref_up[j]).abs() <= 4e-3 * ref_up[j].abs().clamp_min(1.0)).all()), (it, j)
