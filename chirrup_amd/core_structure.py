@@ -106,6 +106,7 @@ class ModelLoadConfig:
     vocab_size: int
     head_size: int
     dtype: torch.dtype = torch.float16       # torch.int8 selects the mm8 (w8a16) channel-mix path
+    att_dtype: torch.dtype = torch.float16   # (not in the reference) torch.int8: receptance / key / value / output and the head as mm8 too
 
     n_head: Optional[int] = field(default=None, init=False)
     n_embd: Optional[int] = field(default=None, init=False)

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CHIRRUP_AMD_LIB") or os.path.join(_HERE, "libchirrup_
 _lib = None
 _lock = threading.Lock()      # worker threads may race to the first load
 
-ABI_VERSION = 2               # CHIRRUP_ABI_VERSION of include/chirrup_amd.h this module's SIGNATURES were written against
+ABI_VERSION = 3               # CHIRRUP_ABI_VERSION of include/chirrup_amd.h this module's SIGNATURES were written against
 
 E_NAMES = {-1: "CHIRRUP_E_SHAPE", -2: "CHIRRUP_E_NULL", -3: "CHIRRUP_E_ALIGN", -4: "CHIRRUP_E_UNSUPPORTED"}
 

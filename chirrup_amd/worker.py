@@ -125,7 +125,8 @@ class Worker:
         if self.model is None:
             self.model = RWKV_x070(model_args(self.model_config.model_path, self.model_config.vocab_size,
                                               self.model_config.head_size),
-                                   ffn_dtype=torch.int8 if self.model_config.dtype == torch.int8 else torch.float16)
+                                   ffn_dtype=torch.int8 if self.model_config.dtype == torch.int8 else torch.float16,
+                                   att_dtype=torch.int8 if getattr(self.model_config, "att_dtype", None) == torch.int8 else torch.float16)
         if self.tokenizer is None:
             self.tokenizer = TRIE_TOKENIZER(self.model_config.vocab_path)
         self._post({"status": "success", "worker_id": self.worker_id, "gpu_id": self.gpu_id,
@@ -511,6 +512,13 @@ class Worker:
             rec, self._inflight = self._inflight, rec
         self._handle_results(rec)
         self.iterations += 1
+        if self.use_graph and (self.iterations & 255) == 0:
+            # the time-mix launch's bounded in-launch waits (include/chirrup_amd.h: rwkv7_tmix_gemms): a wait that gave up left that
+            # step's LoRA outputs undefined -- never seen on a GPU this process has to itself; fatal rather than silently wrong
+            from . import ops
+
+            if ops.chain_status():
+                raise RuntimeError("a time-mix launch gave up waiting for its own workgroups (status word set): results are undefined")
         self.loop_time_recorder.append(time.perf_counter() - t0)
         self._post({"avg_loop_time": sum(self.loop_time_recorder) / len(self.loop_time_recorder),
                     "state_size": self.real_state_size,

@@ -32,8 +32,10 @@ extern "C" {
  * chirrup_abi_version() of the library it loaded before making any other call (chirrup_amd/lib.py does).
  *   1  round 1
  *   2  round 2: skinny_gemm_f16 / _f16_group / _f16_partial gained row_halves (and tile_counters) ahead of `stream`,
- *      skinny_gemm_f16_grouped gained w_tiled, skinny_gemm_group_workspace_bytes gained K, skinny_gemm_select removed */
-#define CHIRRUP_ABI_VERSION 2
+ *      skinny_gemm_f16_grouped gained w_tiled, skinny_gemm_group_workspace_bytes gained K, skinny_gemm_select removed
+ *   3  round 3: chirrup_mm8_fuse gained out_planes (the struct grew); new entry points only otherwise (rwkv7_tmix_gemms,
+ *      rwkv7_tmix_gemms_mm8, rwkv7_tmix_wkv7_fused_mm8, skinny_untile_weight, the clock probes) */
+#define CHIRRUP_ABI_VERSION 3
 int chirrup_abi_version(void);
 const char *chirrup_target_arch(void);
 

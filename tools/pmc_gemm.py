@@ -29,8 +29,8 @@ elif shape == "ffn.key":
     run = lambda W: ops.skinny_linear(x, W, act=1, splits=0, row_halves=True)          # unsplit, 128 tiles x 2 row halves
 elif shape == "att.output":
     Ws = [ops.tile_weight(rnd(C, C)) for _ in range(NW * 2)]
-    x, part = torch.randn(M, C, device=dev).half(), torch.empty(8, M, C, device=dev, dtype=torch.float32)
-    run = lambda W: ops.skinny_linear_partial(x, W, 0, part, row_halves=True)           # split 4 x 32 tiles x 2 row halves
+    x, part = torch.randn(M, C, device=dev).half(), torch.empty(16, M, C, device=dev, dtype=torch.float32)   # (room for the split count
+    run = lambda W: ops.skinny_linear_partial(x, W, 0, part, row_halves=True)           #  the size check assumes: whole rows) split 4 x 32 tiles x 2 row halves
 elif shape == "head":
     Ws = [ops.tile_weight(rnd(65536, C)) for _ in range(2)]
     x = torch.randn(M, C, device=dev).half()
