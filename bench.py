@@ -16,8 +16,14 @@ then the device-side commit of the sampled ids (next input, occurrence += 1, pre
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline      -- the WKV7 kernel: algorithmic bytes B*(270*C+4) per launch / HIP-event launch time
+  roofline_dominant -- the kernel the step spends most of its time in (the 128-column ring GEMM: every launch of a layer
+                   together), algorithmic bytes per step / its summed launch times
   gemm_roofline -- one entry per GEMM launch of a layer (+ head): ALGORITHMIC bytes (weight + x + y; split-K partials are
                    not algorithmic) / HIP-event time of the model's own call, PMC traffic where profiles/ holds it
+                   (tmix_chain = R/K/V + the whole LoRA chain, one launch)
+  ms_per_step_median, ms_per_step_regions -- --repeats further timed regions of --steps steps each (same protocol): boxes differ
+                   by more than a round's gains, the median is what to compare
+  device_clock  -- MHz without load and inside the ffn.key / ffn.value main loops (in-kernel counters)
   mm8           -- the same step with uint8 (w8a16) FFN weights: ms/step, the two u8 GEMMs against N*M + 4(N+M) + 2B(N+M)
   cpu_baseline  -- the CPU oracle (port of the reference arithmetic) on a bounded sample
 """
@@ -658,6 +664,9 @@ def main():
             "step_roofline": {"algorithmic_bytes": step_bytes, "achieved_GBps": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                               "frac_of_hbm_peak": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        from chirrup_amd import ops as _ops2
+        out["tmix_launch_status"] = _ops2.chain_status()      # 0: no bounded in-launch wait of the time-mix launches ever gave up
+        assert out["tmix_launch_status"] == 0, "a time-mix launch gave up waiting for its own workgroups: results undefined"
         if engine_dt is not None:
             ems = engine_dt / a.steps * 1e3
             out["engine"] = {"what": "the same batch through chirrup_amd.worker.Worker.step() (slot pool, graph decode, fused sampler, "
