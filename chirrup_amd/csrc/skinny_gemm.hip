@@ -709,6 +709,7 @@ struct ChainTable {
     int n_lora, n_chain, dsplits, ld_hid, up_N, up_Kimg, up_ldy;
     const f16 *m_rx[4], *m_mx[4];   // uint8 main problems (chain_gemm_kernel<.., true>): scales of problem b and the row sums [M][3] of
     const float *m_S[4];            // its activation prologue -- the rank-1 corrections of the mm8 split form run in the tile's epilogue
+    int warm;                    // 1: the chain workgroups touch their up-projection weights at the start (L2 warm-up)
     int halves;                  // 2: every tile as two workgroups over the two halves of the rows (M > 32); 1: whole rows
     int rkv_splits;              // halves == 1 only: K-slices of an R/K/V tile, reduced inside the launch by the last to arrive (EPI_PAIR)
     float *slab;                 // [down tile][half][slice][16 MT][128] binary32
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
     // Warm THIS XCD's L2 with the up-projection weights this workgroup will stream later (a few hundred KB, contiguous runs of
     // a tile image): issued by the compute waves now, while they wait for the first stage anyway; nobody waits for the data.
     uint32_t warm = 0;
-    if (computes) {
+    if (computes && ct.warm) {
         for (int it = lo; it < hi; it++) {
             const int r = it % per_half, p = r % ct.n_lora, ctile = r / ct.n_lora;
             const unsigned char *w0 = static_cast<const unsigned char *>(ct.uW[p]) + (int64_t)ctile * (ct.up_Kimg / kKB) * (kTileRows * kKB * 2);
@@ -1841,7 +1842,10 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
     const int main_wgs = (gt.first[n_main] * ct.halves * ct.rkv_splits + 15) / 16 * 16;   // whole runs of the XCD-aware tile order
     ct.n_chain = (n_dtiles * ct.halves * ct.dsplits + 7) / 8 * 8;   // the down-projection slices ...
     const int spare = (256 - main_wgs) / 8 * 8;                      // ... and every CU the R/K/V tiles leave idle, for the up-projections
-    if (spare > ct.n_chain) ct.n_chain = spare < 96 ? spare : 96;
+    static const int chain_max = [] { const char *e = getenv("CHIRRUP_CHAIN_MAX"); return e ? atoi(e) : 96; }();      // (tuning / A-B only)
+    static const int chain_warm = [] { const char *e = getenv("CHIRRUP_CHAIN_WARM"); return e ? atoi(e) : 1; }();
+    if (spare > ct.n_chain) ct.n_chain = spare < chain_max ? spare : (chain_max > ct.n_chain ? chain_max / 8 * 8 : ct.n_chain);
+    ct.warm = chain_warm;
     ct.spin_limit = spin_limit > 0 ? spin_limit : 400000;          // x ~0.25 us of s_sleep: ~0.1 s
     const dim3 grid(ct.n_chain + main_wgs);
     ct.stamps = (g_clock_probe && g_clock_pairs >= (int)grid.x * 4) ? g_clock_probe : nullptr;

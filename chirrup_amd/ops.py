@@ -621,7 +621,9 @@ def _chain_state(device, nbytes: int):
         sync = _chain_sync[key] = torch.zeros(_lib.load().rwkv7_tmix_sync_words() + 2, dtype=torch.int32, device=device)
     ws = _chain_ws.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _chain_ws[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        # 32 MiB up front: more than any decode shape needs (slabs <= 4 MiB, split R/K/V partials <= 13 MiB), so that the buffer a
+        # captured graph has recorded is never replaced by a larger one
+        ws = _chain_ws[key] = torch.empty(max(nbytes, 32 << 20), dtype=torch.uint8, device=device)
     return ws, sync
 
 
