@@ -563,6 +563,10 @@ def main():
     L, C = CONFIGS[a.model]
     B = a.bsz
     model = build_model(a.model, dev, fused=not a.no_fused, mm8=a.mm8 or a.mm8_all, tiled=not a.no_tiled, min_embd=a.skinny_min_embd, att8=a.mm8_all)
+    if os.environ.get("CHIRRUP_WARM_PROBE"):            # experiment (tools/exp_warm_step.sh): an L2 warm-up launch in front of every ring GEMM
+        from chirrup_amd import lib as _l
+        _warm_sink = torch.zeros(4, dtype=torch.int32, device=dev)
+        _l.load().skinny_gemm_warm_probe(int(os.environ["CHIRRUP_WARM_PROBE"]), _warm_sink.data_ptr())
     if a.splits is not None:
         model.gemm_splits.update(zip(("rkv", "att_out", "ffn_key", "ffn_value"), (int(v) for v in a.splits.split(","))))
     if a.row_halves is not None:
@@ -607,7 +611,7 @@ def main():
         del state
         engine_dt = engine_iterations(model, B, a, dev, rank, a.steps)
         state = make_state(model, B)
-    gemm_t = gemm_shape_timings(model, B) if rank == 0 else {}
+    gemm_t = gemm_shape_timings(model, B) if (rank == 0 and not os.environ.get("CHIRRUP_BENCH_NO_GEMM_LEG")) else {}      # (the env switch: per-kernel profiles of the step alone)
     clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
     mm8_obj = None
     if rank == 0 and world == 1 and not a.mm8 and not a.mm8_all and not a.no_mm8_leg and not a.no_fused:

@@ -690,8 +690,8 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
 //          slab goes out write-through (sc1), one lane draws the tile's ticket, the LAST slice to arrive adds the slabs in
 //          slice order (its own from LDS; sc1 loads of the others: the fence-free hand-off of MI355X_MICROARCH.md, one
 //          workgroup per CU), applies tanh / sigmoid, stores the binary16 hidden tile write-through and, after every storing
-//          wave has drained and the workgroup's barrier, adds to done[problem][half];
-//       2. a contiguous share of the up-projection tiles: ONE lane polls done[problem][half] (relaxed, s_sleep, bounded),
+//          wave has drained and the workgroup's barrier, adds to done[half] (one counter for all problems of a half);
+//       2. a contiguous share of the up-projection tiles: ONE lane polls done[half] (relaxed, s_sleep, bounded),
 //          ONE agent-scope acquire, vmcnt(0), barrier, then plain LDS-DMA loads of the hidden rows (cdna_hip_programming.md
 //          Guideline 16, recipe R1), the usual main loop and the bias epilogue;
 //       3. a `finished` ticket; the last chain workgroup zeroes the counters for the next launch.
@@ -717,7 +717,7 @@ struct ChainTable {
     int spin_limit;
     unsigned long long *stamps;  // diagnostic (skinny_gemm_clock_probe): 8 x 100-MHz time stamps per workgroup
 };
-constexpr int kChainTickets = 64, kChainDone = 8, kChainPairs = 512, kChainMaxSplits = 4;
+constexpr int kChainTickets = 64, kChainDone = 8, kChainPairs = 512, kChainMaxSplits = 8;
 constexpr int kChainWords = kChainTickets + kChainDone + 2 + kChainPairs;     // ... then the R/K/V tiles' tickets (rkv_splits > 1)
 
 // one K-range of one 128-column tile: prologue, main loop; leaves the sums in `acc` and EVERY wave behind a barrier (the
@@ -933,8 +933,8 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {                                // arrive, then wait for the other K-slices of this tile half (bounded)
-            __hip_atomic_fetch_add(tickets + t.pair_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = chain_wait(tickets + t.pair_id, ct.dsplits, ct.spin_limit, status);
+            const int drawn = __hip_atomic_fetch_add(tickets + t.pair_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = drawn == ct.dsplits - 1 || chain_wait(tickets + t.pair_id, ct.dsplits, ct.spin_limit, status);     // (the last arriver need not look again)
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the loads below the barrier)
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave drains ...
             __syncthreads();                                        // ... before ONE lane signals for all of them
-            if (tid == 0) __hip_atomic_fetch_add(done + p * 2 + half, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_fetch_add(done + half, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // one counter per half, all problems
         }
         __syncthreads();                                            // the staging area is free again
         stamp(3);
@@ -1001,9 +1001,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
             const int half = it / per_half;
             if (!((have >> half) & 1)) {                            // (never with pre: a tile is only run ahead inside an acquired half)
                 if (tid == 0) {
-                    bool got = true;
-                    for (int pp = 0; pp < ct.n_lora && got; pp++)
-                        got = chain_wait(done + pp * 2 + half, (ct.dfirst[pp + 1] - ct.dfirst[pp]) * ct.dsplits, ct.spin_limit, status);
+                    const bool got = chain_wait(done + half, n_dtiles * ct.dsplits, ct.spin_limit, status);     // (one round trip, not one per problem)
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     *flag = got;
@@ -1383,6 +1381,50 @@ extern "C" int skinny_gemm_clock_probe(void *buf, int pairs) {
     return 0;
 }
 
+// Experiment (tools/exp_warm.py): while set, every 128-column launch is preceded by a launch of the same
+// grid whose workgroups touch the first `stages` K-blocks of the W tile the GEMM workgroup with the same id will stream -- what a
+// preceding kernel's idle lanes could do for the GEMM that follows it (same block id -> same XCD -> the lines wait in that XCD's
+// L2).  stages + 100 * mode: mode 1 = the NEXT tile's bytes, 3 = a tile half the matrix away (right memory-side cache, wrong L2),
+// 2 = no loads, `stages` x ~4 us of idling (the control that separates "warm" from "rested").
+static int g_warm_stages = 0;
+static unsigned *g_warm_sink = nullptr;
+extern "C" int skinny_gemm_warm_probe(int stages, void *sink) {
+    g_warm_stages = stages, g_warm_sink = static_cast<unsigned *>(sink);
+    return 0;
+}
+template <bool W8, int EPI>
+__global__ __launch_bounds__(256) void warm_gemm_kernel(const int N, const int K, const int k_slice, const f16 *X, const void *Wv, const int64_t ldw,
+                                                        const BatchStrides bs, const GroupTable gt, int stages, unsigned *sink) {
+    Tile t = resolve_tile<W8, EPI, 1>(N, X, Wv, nullptr, 0, nullptr, nullptr, 32, 0, bs, gt);
+    if (t.ngroup * kTileRows >= t.Np) return;
+    const int mode = stages / 100;
+    stages %= 100;
+    if (mode == 1) t.ngroup = (t.ngroup + 1) * kTileRows < t.Np ? t.ngroup + 1 : 0;
+    if (mode == 3) {
+        const int nt = (t.Np + kTileRows - 1) / kTileRows;
+        t.ngroup = (t.ngroup + nt / 2 + 1) % nt;
+    }
+    if (mode == 2) {
+        for (int i = 0; i < stages; i++) __builtin_amdgcn_s_sleep(127);     // ~4 us each
+        return;
+    }
+    constexpr int kEl = W8 ? 1 : 2, kWTile = kTileRows * kKB * kEl;
+    const int k0 = t.kslice * k_slice;
+    const unsigned char *w = static_cast<const unsigned char *>(t.W);
+    unsigned acc = 0;
+    if (t.w_tiled) {
+        const unsigned char *base = w + ((int64_t)t.ngroup * (K / kKB) + k0 / kKB) * kWTile;
+        for (int ln = threadIdx.x; ln < stages * kWTile / 128; ln += 256) acc ^= *reinterpret_cast<const unsigned *>(base + (int64_t)ln * 128);
+    } else {
+        const int per_row = stages * kKB * kEl / 128;
+        for (int ln = threadIdx.x; ln < kTileRows * per_row; ln += 256) {
+            const int row = ln / per_row, c = ln % per_row;
+            acc ^= *reinterpret_cast<const unsigned *>(w + ((int64_t)(t.ngroup * kTileRows + row) * ldw + k0) * kEl + c * 128);
+        }
+    }
+    if (acc == 0x9e3779b9u && sink) *sink = acc;       // (keeps the loads)
+}
+
 template <bool W8, int EPI>
 int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
                 int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
@@ -1391,6 +1433,11 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
     // tile_of_block deals contiguous runs of tiles to the XCDs only when the workgroup count divides by 8: round the
     // N-group count up (the extra workgroups leave at once)
     while ((grid.x * grid.y * grid.z) & 7) grid.x++;
+    if (g_warm_stages > 0 && bn == 128) {
+        int stages = k_slice / kKB < g_warm_stages % 100 ? k_slice / kKB : g_warm_stages % 100;
+        stages += g_warm_stages / 100 * 100;
+        hipLaunchKernelGGL((warm_gemm_kernel<W8, EPI>), grid, dim3(256), 0, st, N, K, k_slice, X, W, ldw, bs, gt, stages, g_warm_sink);
+    }
     bs.clock = (bn == 128 && g_clock_probe && (int)(grid.x * grid.y * grid.z) <= g_clock_pairs) ? g_clock_probe : nullptr;
 #define GO_K(KERN, MTV)                                                                                                   \
     do {                                                                                                                  \
@@ -1756,10 +1803,12 @@ extern "C" int rwkv7_tmix_sync_words(void) { return kChainWords; }
 extern "C" int rwkv7_tmix_status_word(void) { return kChainTickets + kChainDone + 1; }
 
 namespace {
-int chain_dsplits(int K) {
+// K-slices per down-projection tile (half): as many as the idle CUs can take at once -- the chain's latency at <= 128 rows is
+// what bounds the launch (tools/chain_stamps.py), and an 8-way slice streams 1/8 of K before the first hand-off
+int chain_dsplits(int K, int down_tile_halves = 14, int spare_wgs = 64) {
     const int kb = K / kKB;
-    if (kb % 4 == 0 && kb / 4 >= 4) return 4;
-    if (kb % 2 == 0 && kb / 2 >= 4) return 2;
+    for (int s = kChainMaxSplits; s > 1; s >>= 1)
+        if (kb % s == 0 && kb / s >= 4 && down_tile_halves * s <= (spare_wgs > 64 ? spare_wgs : 64)) return s;
     return 1;
 }
 }  // namespace
@@ -1790,7 +1839,7 @@ extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, co
     int halves, rs;
     chain_plan(M, K, main_tiles, row_halves, halves, rs);
     const int MT = tiles_of(M, halves == 2);
-    int64_t b = (int64_t)tiles * halves * chain_dsplits(K) * (MT * 16) * kTileRows * (int64_t)sizeof(float);
+    int64_t b = (int64_t)tiles * halves * kChainMaxSplits * (MT * 16) * kTileRows * (int64_t)sizeof(float);      // (upper bound: the split count depends on the free CUs)
     if (rs > 1)
         for (int i = 0; i < n_main; i++) b += ((int64_t)rs * M * main_p[i].n * (int64_t)sizeof(float) + 255) / 256 * 256;
     return b + 256;
@@ -1809,7 +1858,7 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
     if (!workspace || !sync) return CHIRRUP_E_NULL;
     if (mis16(workspace) || (reinterpret_cast<uintptr_t>(sync) & 15)) return CHIRRUP_E_ALIGN;
     ChainTable ct{};
-    ct.n_lora = n_lora, ct.dsplits = chain_dsplits(K), ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
+    ct.n_lora = n_lora, ct.ld_hid = ld_hid, ct.up_N = up_n, ct.up_Kimg = up_kimg, ct.up_ldy = up_ldy;
     chain_plan(M, K, gt.first[n_main], row_halves, ct.halves, ct.rkv_splits);
     if (w8) {
         for (int i = 0; i < n_main; i++) ct.m_rx[i] = m_rx[i], ct.m_mx[i] = m_mx[i], ct.m_S[i] = m_S[i];
@@ -1829,6 +1878,9 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
     const int n_dtiles = ct.dfirst[n_lora];
     const int MT = tiles_of(M, ct.halves == 2);
     if (n_dtiles * ct.halves > kChainTickets || gt.first[n_main] > kChainPairs) return CHIRRUP_E_UNSUPPORTED;
+    const int main_wgs = (gt.first[n_main] * ct.halves * ct.rkv_splits + 15) / 16 * 16;   // whole runs of the XCD-aware tile order
+    const int spare = (256 - main_wgs) / 8 * 8;                      // every CU the R/K/V tiles leave idle
+    ct.dsplits = chain_dsplits(K, n_dtiles * ct.halves, spare);
     // workspace: the down-projection slabs, then (split R/K/V) one run of partial planes per R/K/V problem
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     ct.slab = reinterpret_cast<float *>(ws);
@@ -1839,9 +1891,7 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
             ws += ((int64_t)ct.rkv_splits * M * gt.N[i] * (int64_t)sizeof(float) + 255) / 256 * 256;
         }
     ct.sync = static_cast<int *>(sync);
-    const int main_wgs = (gt.first[n_main] * ct.halves * ct.rkv_splits + 15) / 16 * 16;   // whole runs of the XCD-aware tile order
-    ct.n_chain = (n_dtiles * ct.halves * ct.dsplits + 7) / 8 * 8;   // the down-projection slices ...
-    const int spare = (256 - main_wgs) / 8 * 8;                      // ... and every CU the R/K/V tiles leave idle, for the up-projections
+    ct.n_chain = (n_dtiles * ct.halves * ct.dsplits + 7) / 8 * 8;   // the down-projection slices ... and every idle CU, for the up-projections
     static const int chain_max = [] { const char *e = getenv("CHIRRUP_CHAIN_MAX"); return e ? atoi(e) : 96; }();      // (tuning / A-B only)
     static const int chain_warm = [] { const char *e = getenv("CHIRRUP_CHAIN_WARM"); return e ? atoi(e) : 1; }();
     if (spare > ct.n_chain) ct.n_chain = spare < chain_max ? spare : (chain_max > ct.n_chain ? chain_max / 8 * 8 : ct.n_chain);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "rwkv7_tmix_gemms_mm8": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "skinny_gemm_clock_probe": (_i, [_vp, _i]),
+    "skinny_gemm_warm_probe": (_i, [_i, _vp]),
     "chirrup_clock_probe": (_i, [_i, _vp, _vp]),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -268,8 +268,12 @@ class RWKV_x070:
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.chain_tmix_gemms = True                     # ... and the LoRA up-projections in that SAME launch, on the CUs R/K/V leaves idle
-        self.chain_min_rows = 33                         # A/B on one box (gpurun_out/r3i): 13.3B bsz 64 8.36 -> 8.07..8.23 ms, 7.2B bsz 128 5.67 -> 5.61..5.68, bsz 200 7.17 -> 6.93;
-                                                         # at <= 32 rows the chain (fixed hand-off latencies, ~17 us) outlasts the R/K/V tiles (~12 us): 1.5B bsz 32 1.80 -> 1.87 ms
+        # ... from this many rows on.  A/B on one box each (profiles/r03_ab_chain_by_width.txt): from C = 2560 up the single launch wins
+        # at every batch size (2.9B bsz 32 2.86 -> 2.78 ms, bsz 128 4.45 -> 4.20; 7.2B bsz 1 3.46 -> 3.43, bsz 32 3.95 -> 3.90, bsz 128
+        # 5.66 -> 5.55, bsz 200 7.10 -> 6.81; 13.3B bsz 64 8.44 -> 8.28); narrower models stream their R/K/V tiles in less time than
+        # the chain's fixed hand-off latencies take (~18 us at C = 2048) and lose below ~200 rows (1.5B bsz 32 1.82 -> 1.86, bsz 128
+        # 2.49 -> 2.55, bsz 200 3.02 -> 3.04; 0.4B bsz 64 1.63 -> 1.66 but bsz 200 2.25 -> 2.16)
+        self.chain_min_rows = 1 if self.n_embd >= 2560 else 129
         self.skinny_rkv = False                          # r/k/v as one batched launch of the same kernel: 44 vs 55 us alone, no gain beside the LoRA stream
         self.skinny_wide_rows = 1                        # (a separate, higher row bound for att.output / ffn.key: no longer needed)
         self.skinny_head = True                          # the head GEMM too (7.2B: -0.05 ms at bsz 200, -0.17 at 32, -0.25 at 1)

@@ -13,7 +13,9 @@ import torch
 # model name -> (n_layer, n_embd); vocab 65536, head size 64
 CONFIGS = {
     "0.1B": (12, 768),
+    "0.4B": (24, 1024),
     "1.5B": (24, 2048),
+    "2.9B": (32, 2560),
     "7.2B": (32, 4096),
     "13.3B": (61, 4096),
 }

@@ -291,6 +291,10 @@ int skinny_gemm_pair_counters(void);
  * constant 100-MHz counter (s_memrealtime)} into buf (uint64 [2 * pairs]); ticks / (100-MHz ticks) * 100 = the clock in MHz the
  * CU ran the loop at.  buf = NULL switches it off again. */
 int skinny_gemm_clock_probe(void *buf, int pairs);
+/* Experiment (tools/exp_warm.py): while stages > 0 every 128-column launch is preceded by a launch of the
+ * same grid that touches the first `stages % 100` K-blocks of each workgroup's W tile (stages / 100: 1 = the next tile's bytes,
+ * 3 = a tile half the matrix away, 2 = no loads but `stages % 100` x ~4 us of idling); sink: 4 writable bytes.  Process-wide. */
+int skinny_gemm_warm_probe(int stages, void *sink);
 /* The chip's clock without load: one wavefront spins `iters` dependent VALU operations; out (uint64 [2]) receives {shader-clock
  * ticks, 100-MHz ticks}. */
 int chirrup_clock_probe(int iters, void *out, void *stream);
