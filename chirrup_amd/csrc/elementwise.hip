@@ -17,6 +17,7 @@
 // head is 8 consecutive lanes, so head reductions are 3 DPP/shuffle steps inside a wavefront.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/chirrup_amd.h"
 
@@ -40,12 +41,16 @@ __device__ __forceinline__ float head_sum(float v) {   // 8 consecutive lanes = 
     return v;
 }
 
-#ifndef LN_THREADS
-#define LN_THREADS 1024   // one workgroup per row; 1024 lanes keep 4x more loads in flight per row than 256 (step 8.20 -> 8.00 ms)
-#endif
-constexpr int kLnThreads = LN_THREADS;
-constexpr int kLnMaxChunks = 8192 / 8 / LN_THREADS;   // lanes x chunks x 8 channels -> C <= 8192
+// One workgroup per row, ONE 8-channel chunk per lane (a lane with four chunks keeps a quarter of the loads in flight: step 8.20 vs
+// 8.00 ms in round 1): TH = 256 lanes for C <= 2048, 1024 above (512 is built for A/B).  With 256 or 512 lanes a lane has 512 / 256
+// registers to its name instead of 128, and the kernel spends them on latency (HOIST): the LN weights, the lerp coefficients and
+// all eight split-K planes are requested before the first reduction instead of after it -- a row is a chain of dependent
+// round trips (row + planes -> mean -> variance -> LN weights -> lerp coefficients -> stores).  Worth 0.5 % of a step at C = 2048
+// and nothing at C = 4096 (the host picks; rwkv7_add_ln_mix_mm8).
+constexpr int kLnMaxThreads = 1024;
+constexpr int kLnMaxChunks = 1;
 
+template <int TH>
 __device__ __forceinline__ float block_sum(float v, float *red) {
     v = wave_sum(v);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -54,25 +59,27 @@ __device__ __forceinline__ float block_sum(float v, float *red) {
     __syncthreads();
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnThreads / 64; i++) t += red[i];
+    for (int i = 0; i < TH / 64; i++) t += red[i];
     return t;
 }
 
 // three sums at once (the mm8 prologue's S0, S1, S2): one pair of barriers instead of three
+template <int TH>
 __device__ __forceinline__ void block_sum3(float &a, float &b, float &c, float *red3) {
     a = wave_sum(a), b = wave_sum(b), c = wave_sum(c);
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __syncthreads();
-    if (lane == 0) red3[wid] = a, red3[kLnThreads / 64 + wid] = b, red3[2 * (kLnThreads / 64) + wid] = c;
+    if (lane == 0) red3[wid] = a, red3[TH / 64 + wid] = b, red3[2 * (TH / 64) + wid] = c;
     __syncthreads();
     a = b = c = 0.f;
 #pragma unroll
-    for (int i = 0; i < kLnThreads / 64; i++) a += red3[i], b += red3[kLnThreads / 64 + i], c += red3[2 * (kLnThreads / 64) + i];
+    for (int i = 0; i < TH / 64; i++) a += red3[i], b += red3[TH / 64 + i], c += red3[2 * (TH / 64) + i];
 }
 
 // Load row (x + delta) as binary16, return its layer-norm in `out` (binary16 values held as float).
 // If x_out != nullptr the summed row is stored there.
 // x and x_out may alias (the in-place residual update of a decode step), so neither is __restrict__.
+template <int TH>
 __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
                                        const f16 *__restrict__ w, const f16 *__restrict__ b, int C, float eps,
                                        float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
@@ -81,33 +88,37 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                                        const int q_parts = 0, float *q_sh = nullptr) {
     // q_S: this row's mm8 row sums [q_parts][3] in global memory; they are added up (one wave per sum) into q_sh[3] AFTER the
     // loads of the row and of its first four partial planes have been issued, so that their latency is not a stage of its own
+    constexpr bool HOIST = TH < kLnMaxThreads;
+    constexpr int PL = HOIST ? 8 : 4;                  // split-K planes requested together
     const int nchunk = C >> 3;
     float vals[kLnMaxChunks][8];
     float s = 0.f;
     bool q_ready = false;
+    f16x8 wv0 = {}, bv0 = {};                          // (HOIST) the LN weights of this lane's chunk, requested with the row
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
-        const int c = threadIdx.x + q * kLnThreads;
+        const int c = threadIdx.x + q * TH;
         const bool in_row = c < nchunk;
         {
             f16x8 xv = {};
             if (in_row) xv = *reinterpret_cast<const f16x8 *>(x + c * 8);
+            if (HOIST && in_row) wv0 = *reinterpret_cast<const f16x8 *>(w + c * 8), bv0 = *reinterpret_cast<const f16x8 *>(b + c * 8);
             if (dpart) {            // delta = binary16(sum of split-K partials): the GEMM's reduce folded into this prologue
                 float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                // four planes' loads are issued before their adds (in plane order); more in flight buys nothing measurable and costs
-                // 32 registers of the 128 a 1024-lane workgroup has per lane
-                for (int s0 = 0; s0 < dsplits; s0 += 4) {
+                // PL planes' loads are issued before their adds (in plane order): four with 1024 lanes (eight would cost 32 of the
+                // 128 registers a lane has there), all eight otherwise
+                for (int s0 = 0; s0 < dsplits; s0 += PL) {
                     typedef float f32x4_t __attribute__((ext_vector_type(4)));
-                    f32x4_t p[4][2];
+                    f32x4_t p[PL][2];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < PL; u++) {
                         if (in_row && s0 + u < dsplits) {
                             p[u][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8));
                             p[u][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8 + 4));
                         }
                     }
                     if (q_S && !q_ready) {             // (uniform: every lane of the workgroup gets here, in_row or not)
-                        static_assert(kLnThreads >= 3 * 64, "one wave per sum");
+                        static_assert(TH >= 3 * 64, "one wave per sum");
                         if (threadIdx.x < 3 * 64) {
                             const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
                             float tsum = 0.f;
@@ -119,7 +130,7 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                         q_ready = true;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < PL; u++) {
                         if (in_row && s0 + u < dsplits) {
                             acc[0] += p[u][0].x; acc[1] += p[u][0].y; acc[2] += p[u][0].z; acc[3] += p[u][0].w;
                             acc[4] += p[u][1].x; acc[5] += p[u][1].y; acc[6] += p[u][1].z; acc[7] += p[u][1].w;
@@ -151,11 +162,11 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
             }
         }
     }
-    const float mean = block_sum(s, red) / (float)C;
+    const float mean = block_sum<TH>(s, red) / (float)C;
     float s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
-        const int c = threadIdx.x + q * kLnThreads;
+        const int c = threadIdx.x + q * TH;
         if (c < nchunk) {
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -164,13 +175,13 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
             }
         }
     }
-    const float rstd = 1.0f / sqrtf(block_sum(s2, red) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(block_sum<TH>(s2, red) / (float)C + eps);
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
-        const int c = threadIdx.x + q * kLnThreads;
+        const int c = threadIdx.x + q * TH;
         if (c < nchunk) {
-            const f16x8 wv = *reinterpret_cast<const f16x8 *>(w + c * 8);
-            const f16x8 bv = *reinterpret_cast<const f16x8 *>(b + c * 8);
+            const f16x8 wv = HOIST ? wv0 : *reinterpret_cast<const f16x8 *>(w + c * 8);
+            const f16x8 bv = HOIST ? bv0 : *reinterpret_cast<const f16x8 *>(b + c * 8);
 #pragma unroll
             for (int e = 0; e < 8; e++) out[q][e] = (float)h((vals[q][e] - mean) * rstd * (float)wv[e] + (float)bv[e]);
         }
@@ -178,14 +189,15 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
 }
 
 // One workgroup per R consecutive (b, t) rows of a sequence.
-template <int NMIX>
-__global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
+template <int NMIX, int TH>
+__global__ __launch_bounds__(TH) void add_ln_mix_kernel(
     const int T, const int C, const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
     const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride,
     const chirrup_mm8_fuse fz, const int R) {
-    __shared__ float red[3 * (kLnThreads / 64)];
+    constexpr bool HOIST = TH < kLnMaxThreads;
+    __shared__ float red[3 * (TH / 64)];
     // A workgroup takes R consecutive tokens of one sequence: the token shift of row t needs LN(row t-1), which is the row
     // this workgroup normalised one trip earlier -- only the first of its rows recomputes its predecessor (R = 1, one row per
     // workgroup, recomputes it for every row with t > 0: twice the loads and arithmetic at T > 1).
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         if (t0 == 0) {
 #pragma unroll
             for (int q = 0; q < kLnMaxChunks; q++) {
-                const int c = threadIdx.x + q * kLnThreads;
+                const int c = threadIdx.x + q * TH;
                 if (c < nchunk) {
                     const f16x8 pv = *reinterpret_cast<const f16x8 *>(prev_in + slot * C + c * 8);
 #pragma unroll
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
             }
         } else {
             const int64_t rp = ((int64_t)bb * T + t0 - 1) * C;
-            ln_row(x + rp, delta ? delta + rp : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red, dpart ? dpart + rp : nullptr, dsplits,
+            ln_row<TH>(x + rp, delta ? delta + rp : nullptr, nullptr, ln_w, ln_b, C, eps, prev, red, dpart ? dpart + rp : nullptr, dsplits,
                    dsplit_stride, q_rx, q_mx, fz.in_S ? fz.in_S + ((int64_t)bb * T + t0 - 1) * fz.in_S_parts * 3 : nullptr,
                    fz.in_S_parts, qsum[1]);
         }
@@ -223,12 +235,17 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         const int row = bb * T + t;
         const int64_t ro = (int64_t)row * C;
         const float *q_row = fz.in_S ? fz.in_S + (int64_t)row * fz.in_S_parts * 3 : nullptr;
-        ln_row(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
+        f16x8 mvh[NMIX ? NMIX : 1];                   // (HOIST) the lerp coefficients of this lane's chunk, requested with the row
+        if (HOIST && NMIX > 0 && (int)threadIdx.x < nchunk) {
+#pragma unroll
+            for (int m = 0; m < NMIX; m++) mvh[m] = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + threadIdx.x * 8);
+        }
+        ln_row<TH>(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
                dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0]);
         if (NMIX == 0) {
 #pragma unroll
             for (int q = 0; q < kLnMaxChunks; q++) {
-                const int c = threadIdx.x + q * kLnThreads;
+                const int c = threadIdx.x + q * TH;
                 if (c < nchunk) {
                     f16x8 o;
 #pragma unroll
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
         for (int m = 0; m < (NQ ? NQ : 1); m++) ps[m][0] = ps[m][1] = ps[m][2] = 0.f;
 #pragma unroll
         for (int q = 0; q < kLnMaxChunks; q++) {
-            const int c = threadIdx.x + q * kLnThreads;
+            const int c = threadIdx.x + q * TH;
             if (c < nchunk) {
                 float dx[8];
                 f16x8 cv;
@@ -257,7 +274,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
                 if (t == T - 1) *reinterpret_cast<f16x8 *>(prev_out + slot * C + c * 8) = cv;
 #pragma unroll
                 for (int m = 0; m < NMIX; m++) {
-                    const f16x8 mv = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
+                    const f16x8 mv = HOIST ? mvh[m] : *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + c * 8);
                     f16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; e++) o[e] = h(cur[q][e] + (float)h(dx[e] * (float)mv[e]));
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(kLnThreads) void add_ln_mix_kernel(
 #pragma unroll
             for (int m = 0; m < NQ; m++) {
                 if (m < n_q) {                                         // (uniform over the workgroup)
-                    block_sum3(ps[m][0], ps[m][1], ps[m][2], red);
+                    block_sum3<TH>(ps[m][0], ps[m][1], ps[m][2], red);
                     if (threadIdx.x == 0) {
                         float *dst = fz.out_S + ((int64_t)m * rows_total + row) * 3;
                         dst[0] = ps[m][0], dst[1] = ps[m][1], dst[2] = ps[m][2];
@@ -444,7 +461,7 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
     if (q.out_xs && (n_mix == 0 || !q.out_ry || !q.out_my || !q.out_S)) return q.out_xs && n_mix == 0 ? CHIRRUP_E_UNSUPPORTED : CHIRRUP_E_NULL;
     if (q.out_xs && (q.out_planes < 0 || q.out_planes > (n_mix == 1 ? 1 : 3))) return CHIRRUP_E_SHAPE;
     if (mis16(q.in_rx) || mis16(q.in_mx) || mis16(q.out_ry) || mis16(q.out_my) || mis16(q.out_xs)) return CHIRRUP_E_ALIGN;
-    if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 63) || C > kLnMaxThreads * kLnMaxChunks * 8) return CHIRRUP_E_SHAPE;
     if (!(n_mix == 0 || n_mix == 1 || n_mix == 6)) return CHIRRUP_E_UNSUPPORTED;
     if (!x || !ln_w || !ln_b || !out) return CHIRRUP_E_NULL;
     if (n_mix > 0 && (!prev_in || !prev_out || !mix)) return CHIRRUP_E_NULL;
@@ -466,13 +483,25 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
         R = R < 2 ? 2 : (R > 8 ? 8 : R);
         if (R > T) R = T;
     }
-    const dim3 grid((unsigned)(B * ((T + R - 1) / R))), block(kLnThreads);
+    static const int forced_th = [] { const char *e = getenv("CHIRRUP_LN_THREADS"); return e ? atoi(e) : 0; }();     // (A/B only: 1024 = round 2's kernel)
+    // one 8-channel chunk per lane.  A/B on one box (gpurun_out/r3_ln_ab.log): 256 lanes with the hoisted loads win 0.5 % of the step at
+    // C = 2048 (1.5B bsz 32: 1.806 -> 1.797 ms); 512 lanes at C = 4096 LOSE 0.5-1 % against 1024 lanes of which half idle (7.2B bsz 200
+    // 6.75 -> 6.79, bsz 32 3.91 -> 3.93; 13.3B bsz 64 7.37 -> 7.42) -- wider rows keep the 1024-lane form
+    const int TH = forced_th == 1024 ? 1024 : (forced_th == 512 && C <= 4096 ? 512 : (C <= 2048 ? 256 : 1024));
+    const dim3 grid((unsigned)(B * ((T + R - 1) / R))), block(TH);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
              (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx, delta_partials, \
              delta_splits, (int64_t)B * T * C, q, R
-    if (n_mix == 0) hipLaunchKernelGGL(add_ln_mix_kernel<0>, grid, block, 0, st, ARGS);
-    else if (n_mix == 1) hipLaunchKernelGGL(add_ln_mix_kernel<1>, grid, block, 0, st, ARGS);
-    else hipLaunchKernelGGL(add_ln_mix_kernel<6>, grid, block, 0, st, ARGS);
+#define LN_GO(NM)                                                                                  \
+    do {                                                                                           \
+        if (TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256>), grid, block, 0, st, ARGS);  \
+        else if (TH == 512) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 512>), grid, block, 0, st, ARGS); \
+        else hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024>), grid, block, 0, st, ARGS);           \
+    } while (0)
+    if (n_mix == 0) LN_GO(0);
+    else if (n_mix == 1) LN_GO(1);
+    else LN_GO(6);
+#undef LN_GO
 #undef ARGS
     return (int)hipGetLastError();
 }
