@@ -65,6 +65,7 @@ def parse():
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
     p.add_argument("--chain-min-rows", type=int, default=None, help="batch rows from which R/K/V and the LoRA chain share one launch, tuning only")
     p.add_argument("--no-chain", action="store_true", help="LoRA up-projections as a launch of their own instead of inside the R/K/V launch, A/B only")
+    p.add_argument("--torch-commit", action="store_true", help="the sampled ids' table updates as torch ops instead of the commit kernel, A/B only")
     p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
     p.add_argument("--lora-row-halves", type=int, default=None, help="1/0: LoRA up-projections as two row halves per tile, A/B only")
@@ -458,10 +459,13 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None, repeats=0):
             ops.penalize_argmax(logits, out=ids_dev)     # plain arg-max (temperature 0, samplers.py:195-197)
         else:
             ops.penalize_argmax(logits, occurrence, alpha_presence, decay, freq, slots, out=ids_dev)
-            il = ids_dev.long()                          # Worker._commit_sampled
-            last_ids.index_copy_(0, slots64, ids_dev)
-            occurrence.index_put_((slots64, il), penalty_weight[il], accumulate=True)
-            alpha_presence[slots64, il] = presence[slots64, 0]
+            if a.torch_commit:                           # round 2's Worker._commit_sampled: torch ops, ~12 eager launches (A/B)
+                il = ids_dev.long()
+                last_ids.index_copy_(0, slots64, ids_dev)
+                occurrence.index_put_((slots64, il), penalty_weight[il], accumulate=True)
+                alpha_presence[slots64, il] = presence[slots64, 0]
+            else:                                        # Worker._commit_sampled
+                ops.commit_sampled(ids_dev, slots, last_ids, occurrence, penalty_weight, alpha_presence, presence)
         i = n_steps[0] & 1
         if a.sync_ids:
             ids_host[i].copy_(ids_dev, non_blocking=False)

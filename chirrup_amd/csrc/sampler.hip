@@ -111,6 +111,38 @@ extern "C" int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurren
 }
 
 // ------------------------------------------------------------------------------------------------
+// Device-side consequences of the sampled ids (chirrup/worker.py:527-535; chirrup_amd/worker.py::_commit_sampled): the next
+// decode input of the slot, occurrence[slot][id] += penalty_weight[id] (0 for the no-penalty ids), alpha_presence[slot][id] =
+// presence[slot].  One lane per row: as torch ops (index_copy_, a gather, index_put_(accumulate=True) -- which sorts its
+// indices --, an indexed assignment and their bounds-check kernels) this was ~12 eager launches behind every decode step.
+namespace {
+__global__ __launch_bounds__(256) void commit_sampled_kernel(const int n, const int V, const int32_t *__restrict__ ids,
+                                                             const int32_t *__restrict__ slot_idx, int32_t *__restrict__ last_ids,
+                                                             float *__restrict__ occurrence, const float *__restrict__ penalty_weight,
+                                                             float *__restrict__ alpha, const float *__restrict__ presence,
+                                                             const int64_t presence_stride) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= n) return;
+    const int id = ids[row];
+    const int64_t slot = slot_idx ? (int64_t)slot_idx[row] : (int64_t)row;
+    last_ids[slot] = id;
+    if (id < 0 || id >= V) return;                     // (cannot be produced by the samplers; the tables are left alone)
+    atomicAdd(occurrence + slot * V + id, penalty_weight[id]);     // (slots of a batch are distinct; the atomic keeps accumulate=True's meaning if not)
+    alpha[slot * V + id] = presence[slot * presence_stride];
+}
+}  // namespace
+
+extern "C" int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
+                                    const float *penalty_weight, float *alpha_presence, const float *presence,
+                                    int64_t presence_stride, void *stream) {
+    if (n <= 0 || V <= 0 || presence_stride < 0) return CHIRRUP_E_SHAPE;
+    if (!ids || !last_ids || !occurrence || !penalty_weight || !alpha_presence || !presence) return CHIRRUP_E_NULL;
+    hipLaunchKernelGGL(commit_sampled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, V, ids,
+                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Sort-free top-p / top-k / temperature sampling for the rows that are NOT greedy.
 //
 // Semantics of sample_logits_rwkv_pip_compatible (chirrup/utils/samplers.py:171-255): probs =

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rwkv7_tmix_wkv7_fused_mm8": (_i, [_i, _i, _i, _i] + [_vp] * 14 + [ctypes.c_float, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rwkv7_lora_act": (_i, [_i, _i, _i64, _vp, _vp]),
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
+    "rwkv7_commit_sampled": (_i, [_i, _i] + [_vp] * 7 + [_i64, _vp]),
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "skinny_gemm_splits": (_i, [_i, _i, _i, _i]),

@@ -427,6 +427,30 @@ def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=
     return out
 
 
+def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence) -> None:
+    """ONE launch for what sampling `ids` (int32 [n]) for the slots `slot_idx` (int32 [n] or None) changes on the device
+    (chirrup/worker.py:527-535): last_ids[slot] = id, occurrence[slot, id] += penalty_weight[id], alpha_presence[slot, id] =
+    presence[slot, 0].  Tables fp32 [n_slots, V] contiguous, penalty_weight fp32 [V], presence fp32 [n_slots, 1] or [n_slots]."""
+    n = ids.numel()
+    if n == 0:
+        return
+    n_slots, V = occurrence.shape
+    _chk(ids, "ids", torch.int32, (n,))
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (n,))
+    elif n_slots != n:
+        raise _lib.ChirrupAmdError("tables have a different row count and no slot_idx")
+    _chk(last_ids, "last_ids", torch.int32, (n_slots,))
+    for name, t, shape in (("occurrence", occurrence, (n_slots, V)), ("alpha_presence", alpha_presence, (n_slots, V)),
+                           ("penalty_weight", penalty_weight, (V,))):
+        _chk(t, name, torch.float32, shape)
+    if not presence.is_cuda or presence.dtype != torch.float32 or presence.dim() not in (1, 2) or presence.shape[0] != n_slots:
+        raise _lib.ChirrupAmdError("presence: expected GPU fp32 [n_slots, 1] or [n_slots]")
+    rc = _lib.load().rwkv7_commit_sampled(n, V, _ptr(ids), _ptr(slot_idx), _ptr(last_ids), _ptr(occurrence), _ptr(penalty_weight),
+                                          _ptr(alpha_presence), _ptr(presence), presence.stride(0), _stream())
+    _lib.check(rc, "rwkv7_commit_sampled")
+
+
 class TiledWeight:
     """A [N, K] fp16 weight re-laid as 16-KiB tile images for the ring GEMM (include/chirrup_amd.h:
     skinny_tile_weight).  Accepted wherever the skinny_* wrappers take a weight."""

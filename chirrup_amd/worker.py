@@ -93,6 +93,7 @@ class Worker:
         self.model, self.tokenizer = model, tokenizer   # may be injected (tests use a fake backend)
         self._penalize_argmax = penalize_argmax if penalize_argmax is not None else ops.penalize_argmax
         self._sample_topp = ops.sample_topp if penalize_argmax is None else None     # fake backends use the torch sampler
+        self._commit_kernel = ops.commit_sampled if penalize_argmax is None else None  # ... and torch ops for the commit
         self.batch_state = None
         # where exported prefix states live: None = the pool's own device (HBM-resident prefix cache:
         # 17-33 MB device-to-device copies instead of two PCIe transfers per cache hit); "cpu" = the
@@ -264,6 +265,10 @@ class Worker:
     def _commit_sampled(self, ids: torch.Tensor, didx: torch.Tensor):
         """Device-side consequences of sampling `ids` for the slots `didx`: the next decode input and the
         repetition-penalty state (worker.py:527-535: occurrence += 1 except for the no-penalty ids, presence)."""
+        if self._commit_kernel is not None:                # one launch instead of ~12 eager ones behind every decode step
+            self._commit_kernel(ids, didx, self.last_ids, self.occurrence, self.penalty_weight, self.alpha_presence_vector,
+                                self.presence_penalty_tensor)
+            return
         dl, il = didx.long(), ids.long()
         self.last_ids.index_copy_(0, dl, ids)
         self.occurrence.index_put_((dl, il), self.penalty_weight[il], accumulate=True)

@@ -390,6 +390,13 @@ int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void
 int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const float *alpha_presence,
                           const void *penalty_decay, const void *frequency_penalty, const int32_t *slot_idx,
                           int32_t *ids, void *stream);
+/* The device-side consequences of sampling ids[row] for slot slot_idx[row] (row when slot_idx is NULL), row < n
+ * (reference: chirrup/worker.py:527-535): last_ids[slot] = id; occurrence[slot][id] += penalty_weight[id];
+ * alpha_presence[slot][id] = presence[slot * presence_stride].  occurrence / alpha_presence fp32 [n_slots][V],
+ * penalty_weight fp32 [V], last_ids int32 [n_slots].  An id outside [0, V) only updates last_ids. */
+int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
+                         const float *penalty_weight, float *alpha_presence, const float *presence, int64_t presence_stride,
+                         void *stream);
 
 /*
  * Sort-free top-p / top-k / temperature sampling of n_rows rows of `logits` (binary16 [B][V], V <= 65536,

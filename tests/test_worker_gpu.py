@@ -386,3 +386,40 @@ def test_worker_values_in_the_hand_written_gemm_regime():
         else:
             exact += 1
     assert exact >= n_req * 3 // 4, exact               # near-ties are rare: most streams agree to the last token
+
+
+def test_commit_sampled_kernel_matches_the_torch_ops():
+    """ops.commit_sampled == Worker._commit_sampled's torch form (chirrup/worker.py:527-535): last ids, occurrence increments by the
+    per-token weight (0 for the no-penalty ids), presence entries -- on a slot subset in scrambled order, bit for bit; a repeated
+    slot accumulates like index_put_(accumulate=True); an id outside the vocabulary only lands in last_ids."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(0)
+    dev, n_slots, V, n = "cuda", 37, 4096, 21
+    occ = torch.rand(n_slots, V, device=dev)
+    alpha = torch.rand(n_slots, V, device=dev)
+    pw = torch.ones(V, device=dev)
+    pw[[0, 11, 33, 261]] = 0.0
+    presence = torch.rand(n_slots, 1, device=dev)
+    last = torch.full((n_slots,), -5, dtype=torch.int32, device=dev)
+    slots = torch.randperm(n_slots, device=dev)[:n].to(torch.int32)
+    ids = torch.randint(0, V, (n,), device=dev, dtype=torch.int32)
+    ids[:4] = torch.tensor([0, 11, 33, 261], dtype=torch.int32, device=dev)          # no-penalty ids
+    want_occ, want_alpha, want_last = occ.clone(), alpha.clone(), last.clone()
+    dl, il = slots.long(), ids.long()
+    want_last.index_copy_(0, dl, ids)
+    want_occ.index_put_((dl, il), pw[il], accumulate=True)
+    want_alpha[dl, il] = presence[dl, 0]
+    ops.commit_sampled(ids, slots, last, occ, pw, alpha, presence)
+    assert torch.equal(last, want_last) and torch.equal(occ, want_occ) and torch.equal(alpha, want_alpha)
+    # no slot_idx: rows are slots
+    occ2, alpha2, last2 = torch.zeros(n, V, device=dev), torch.zeros(n, V, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)
+    ops.commit_sampled(ids, None, last2, occ2, pw, alpha2, presence[:n].contiguous())
+    assert torch.equal(last2, ids) and float(occ2.sum()) == float(pw[il].sum())
+    assert torch.equal(alpha2[torch.arange(n, device=dev), il], presence[:n, 0])
+    # a slot twice in one call accumulates; an id outside [0, V) touches no table
+    occ3, alpha3, last3 = torch.zeros(4, V, device=dev), torch.zeros(4, V, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+    ops.commit_sampled(torch.tensor([7, 7, V + 3, -1], dtype=torch.int32, device=dev), torch.tensor([2, 2, 1, 3], dtype=torch.int32, device=dev),
+                       last3, occ3, pw, alpha3, torch.ones(4, 1, device=dev))
+    assert float(occ3[2, 7]) == 2.0 and float(occ3.sum()) == 2.0 and float(alpha3.sum()) == 1.0
+    assert last3.tolist() == [0, V + 3, 7, -1]
