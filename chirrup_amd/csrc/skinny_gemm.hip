@@ -124,6 +124,7 @@ struct BatchStrides {
     Mm8Epilogue q8;    // EPI_MM8
     int *counters;     // EPI_PAIR: one zero-initialised int per tile; the second arriver leaves it zero again
     unsigned long long *clock;   // diagnostic (skinny_gemm_clock_probe): per workgroup {shader-clock ticks, 100-MHz ticks} of the main loop
+    unsigned long long *timeline;   // ... and, behind the pairs, 4 absolute 100-MHz stamps per workgroup: kernel entry, loop start, loop end, epilogue done
     int row_halves;    // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
@@ -286,13 +287,23 @@ __device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int 
 // group (half of the m-tiles of one k-step) ahead of the MFMAs that use them; the sched_barriers pin that order -- left
 // alone, the scheduler sinks every ds_read to just before its MFMA (fewer live registers) and each MFMA then waits a full
 // LDS latency.  `mid()` runs between the two k-steps (the wide kernel issues its W loads there).
+// Diagnostic builds only (make ablate A=<bits>; tools/ablate_gemm.sh): RING_ABLATE bit 0 = no MFMAs (the fragments are still read),
+// bit 1 = the loader waves issue no loads, bit 2 = no fragment reads (the MFMAs run on whatever the registers hold), bit 3 = the
+// epilogue's stores non-temporal.
+#ifndef RING_ABLATE
+#define RING_ABLATE 0
+#endif
 template <int MT, typename Mid>
 __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 (&wf)[2][2], const int c, const int q, f32x4 (&acc)[2][MT],
                                            Mid &&mid) {
     constexpr int HA = (MT + 1) / 2, HB = MT - HA;     // m-tiles of the two groups of a k-step
     auto xfrag = [&](int ks, int mt) {
         const int m = mt * 16 + c;
+#if RING_ABLATE & 4
+        return f16x8{(f16)m, (f16)ks, 0, 0, 0, 0, 0, 0};
+#else
         return *reinterpret_cast<const f16x8 *>(xt + m * 128 + (((4 * ks + q) ^ ((m >> 1) & 7)) << 4));
+#endif
     };
     f16x8 bq[2][HA];
 #pragma unroll
@@ -313,8 +324,14 @@ __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 
 #pragma unroll
         for (int j = 0; j < count; j++) {
 #pragma unroll
-            for (int nt = 0; nt < 2; nt++)
+            for (int nt = 0; nt < 2; nt++) {
+#if RING_ABLATE & 1
+                typedef int i32x4 __attribute__((ext_vector_type(4)));
+                asm volatile("" ::"v"(__builtin_bit_cast(i32x4, wf[nt][ks])), "v"(__builtin_bit_cast(i32x4, bq[g & 1][j])));
+#else
                 acc[nt][first + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][ks], bq[g & 1][j], acc[nt][first + j], 0, 0, 0);
+#endif
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -354,7 +371,11 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
                 const float v = e < 4 ? va[e] : vb[e - 4];
                 o[e] = (f16)apply_act(t.bias ? v + (float)bv[e] : v, t.act);
             }
+#if RING_ABLATE & 8
+            __builtin_nontemporal_store(o, reinterpret_cast<f16x8 *>(t.Y + (int64_t)m * t.ldy + n));
+#else
             *reinterpret_cast<f16x8 *>(t.Y + (int64_t)m * t.ldy + n) = o;
+#endif
         }
         return;
     }
@@ -369,7 +390,11 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
             for (int e = 0; e < 4; e++) o[e] = (f16)apply_act(t.bias ? v[e] + (float)t.bias[n + e] : v[e], t.act);
             *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
         } else {
+#if RING_ABLATE & 8
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * plane_rows + m) * t.Np + n));
+#else
             *reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * plane_rows + m) * t.Np + n) = v;
+#endif
         }
     }
 }
@@ -594,6 +619,7 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     const bool computes = wave < 4;
     const int lt = tid & 255, lw = wave & 3;
     const bool short_x = (MT & 1) && lw >= 2;         // this loader wave sits out the half round
+    const unsigned long long t_entry = bs.timeline ? __builtin_amdgcn_s_memrealtime() : 0;
     const Tile t = resolve_tile<W8, EPI, MT>(N, X, Wv, Y, ldy, bias, part, M, ldx, bs, gt);
     const int n_base = t.ngroup * BN;
     if (n_base >= t.Np) return;                        // padding workgroup (launch_gemm rounds the grid up for the XCD map)
@@ -613,6 +639,7 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
 
     const Loader<W8> ld(t, t.M, ldx, ldw, K, lt);
     auto stage = [&](int kb) {
+#if !(RING_ABLATE & 2)
         const int k0 = k_begin + kb * kKB;
         unsigned char *xb = xring + (kb % D) * kXBytes, *wb = wring + (kb % D) * kWBytes;
 #pragma unroll
@@ -622,6 +649,7 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         }
 #pragma unroll
         for (int i = 0; i < kWLoads; i++) ld.w_round(n_base, i, k0, wb + (i * 256 + lw * 64) * 16);
+#endif
     };
 
     // at step kb the ring holds stages kb .. kb+D-2, in issue order
@@ -632,18 +660,28 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     }
     unsigned long long clk0 = 0, rt0 = 0;
     if (bs.clock) clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-    for (int kb = 0; kb < nkb; kb++) {
-        if (!computes) {
+    // One loop per role, the same number of barriers in both: with the two roles as branches of ONE loop body the accumulators
+    // were merged at the loop latch (the loader waves "carry" theirs through), and for every tile count but 7 the register
+    // allocator paid for that merge with a copy of every accumulator register per K-block -- 103 v_mov per 52 MFMAs at 13
+    // tiles, 412 of the compute waves' ~2000 cycles per K-block (profiles/r03_gemm_main_loop_bound.txt).
+    if (!computes) {
+        for (int kb = 0; kb < nkb; kb++) {
             const int left = nkb - 1 - kb, ahead = left < D - 2 ? left : D - 2;
             if (short_x) wait_stages_ahead<kXRounds - 1 + kWLoads>(ahead);
             else wait_stages_ahead<kXRounds + kWLoads>(ahead);
-        }
-        asm volatile("s_barrier" ::: "memory");        // every loader's share landed; the slot restaged below is no longer read
-        if (!computes) {
+            asm volatile("s_barrier" ::: "memory");    // every loader's share landed; the slot restaged below is no longer read
             if (kb + D - 1 < nkb) stage(kb + D - 1);
-        } else {
+        }
+    } else {
+        for (int kb = 0; kb < nkb; kb++) {
+            asm volatile("s_barrier" ::: "memory");
             f16x8 wf[2][2];
+#if RING_ABLATE & 4
+            for (int a_ = 0; a_ < 2; a_++)
+                for (int b_ = 0; b_ < 2; b_++) wf[a_][b_] = f16x8{(f16)kb, (f16)c, 0, 0, 0, 0, 0, 0};
+#else
             read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
+#endif
             mma_kblock<MT>(xring + (kb % D) * kXBytes, wf, c, q, acc, [] {});
         }
     }
@@ -651,6 +689,7 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
     if (bs.clock && tid == 0) {
         const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         bs.clock[2 * wg] = __builtin_amdgcn_s_memtime() - clk0, bs.clock[2 * wg + 1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        if (bs.timeline) bs.timeline[4 * wg] = t_entry, bs.timeline[4 * wg + 1] = rt0, bs.timeline[4 * wg + 2] = __builtin_amdgcn_s_memrealtime();
     }
     float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*16 rows x 528 B <= its size)
     __syncthreads();                                   // every compute wave is past its last fragment read
@@ -676,6 +715,10 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         if (*flag) combine_store<256>(stg, t.M, n_base, t, t.kslice, (int)gridDim.y);
     } else {
         store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
+    }
+    if (bs.timeline && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bs.timeline[4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -773,16 +816,17 @@ __device__ __forceinline__ void chain_mainloop(const Tile &t, const int ldx, con
         for (int p = 0; p < D - 1; p++)
             if (p < nkb) chain_stage<MT, D, W8>(ld, p, k_begin, n_base, smem);
     }
-    for (int kb = 0; kb < nkb; kb++) {
-        if (!computes) {
+    if (!computes) {                                   // (one loop per role: see ring_gemm_kernel)
+        for (int kb = 0; kb < nkb; kb++) {
             const int left = nkb - 1 - kb, ahead = left < D - 2 ? left : (D - 2 > 0 ? D - 2 : 0);
             if (short_x) wait_stages_ahead<kXRounds - 1 + kWLoads>(ahead);
             else wait_stages_ahead<kXRounds + kWLoads>(ahead);
-        }
-        asm volatile("s_barrier" ::: "memory");
-        if (!computes) {
+            asm volatile("s_barrier" ::: "memory");
             if (kb + D - 1 < nkb) chain_stage<MT, D, W8>(ld, kb + D - 1, k_begin, n_base, smem);
-        } else {
+        }
+    } else {
+        for (int kb = 0; kb < nkb; kb++) {
+            asm volatile("s_barrier" ::: "memory");
             f16x8 wf[2][2];
             read_w_frags<W8>(wring + (kb % D) * kWBytes, wave * 32, c, q, wf);
             mma_kblock<MT>(xring + (kb % D) * kXBytes, wf, c, q, acc, [] {});
@@ -1439,6 +1483,7 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
         hipLaunchKernelGGL((warm_gemm_kernel<W8, EPI>), grid, dim3(256), 0, st, N, K, k_slice, X, W, ldw, bs, gt, stages, g_warm_sink);
     }
     bs.clock = (bn == 128 && g_clock_probe && (int)(grid.x * grid.y * grid.z) <= g_clock_pairs) ? g_clock_probe : nullptr;
+    bs.timeline = (bs.clock && (int)(grid.x * grid.y * grid.z) * 3 <= g_clock_pairs) ? g_clock_probe + 2 * (grid.x * grid.y * grid.z) : nullptr;
 #define GO_K(KERN, MTV)                                                                                                   \
     do {                                                                                                                  \
         auto kern = KERN<MTV, W8, EPI>;                                                                                   \

@@ -289,7 +289,9 @@ int skinny_gemm_pair_counters(void);
 /* Diagnostic for bench.py / tools (process-wide, not thread-safe): while buf != NULL every 128-column GEMM launch of at most
  * `pairs` workgroups writes, per workgroup, the duration of its main loop as {shader-clock ticks (s_memtime), ticks of the
  * constant 100-MHz counter (s_memrealtime)} into buf (uint64 [2 * pairs]); ticks / (100-MHz ticks) * 100 = the clock in MHz the
- * CU ran the loop at.  buf = NULL switches it off again. */
+ * CU ran the loop at.  When pairs >= 3 x the launch's workgroups, 4 absolute 100-MHz stamps per workgroup follow the pairs
+ * (buf[2 * workgroups + 4 * wg + {0..3}]: kernel entry, main loop start, main loop end, epilogue stores done): the launch's
+ * timeline (tools/gemm_timeline.py).  buf = NULL switches it off again. */
 int skinny_gemm_clock_probe(void *buf, int pairs);
 /* Experiment (tools/exp_warm.py): while stages > 0 every 128-column launch is preceded by a launch of the
  * same grid that touches the first `stages % 100` K-blocks of each workgroup's W tile (stages / 100: 1 = the next tile's bytes,

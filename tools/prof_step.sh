@@ -10,7 +10,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:14]:
+for r in rows[:22]:
     print("    %-60s calls %6s avg %8.2f us total %8.2f ms" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY
 rm -rf $d
