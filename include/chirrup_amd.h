@@ -300,6 +300,9 @@ int skinny_gemm_warm_probe(int stages, void *sink);
 /* The chip's clock without load: one wavefront spins `iters` dependent VALU operations; out (uint64 [2]) receives {shader-clock
  * ticks, 100-MHz ticks}. */
 int chirrup_clock_probe(int iters, void *out, void *stream);
+/* Launch-cost probe (tools/launch_cost.py): `grid` workgroups of `block` lanes that hold lds_bytes of LDS, idle for sleep x ~4 us
+ * and do nothing else. */
+int chirrup_noop_launch(int grid, int block, int lds_bytes, int sleep, void *sink, void *stream);
 int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *problems, int M, int K, int ldx, int64_t ldw, int splits,
                           int row_halves, void *workspace, void *tile_counters, void *stream);
 int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled, const void *bias,
