@@ -293,10 +293,18 @@ __device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int 
 #ifndef RING_ABLATE
 #define RING_ABLATE 0
 #endif
+#ifndef RING_INTERLEAVE
+#define RING_INTERLEAVE 1
+#endif
 template <int MT, typename Mid>
 __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 (&wf)[2][2], const int c, const int q, f32x4 (&acc)[2][MT],
                                            Mid &&mid) {
     constexpr int HA = (MT + 1) / 2, HB = MT - HA;     // m-tiles of the two groups of a k-step
+    // IL: the next group's fragment reads go out one behind every tile's two MFMAs (in their shadow) instead of as a burst in
+    // front of the group -- a burst of 6-7 ds_read_b128 costs the wave ~100 issue cycles in which no MFMA starts.  Compute waves
+    // alone (no loads, 200 rows): ffn.key 22.9 -> 21.2 us, ffn.value 19.4 -> 17.4, their uint8 forms 26.6 -> 24.8 and 21.4 -> 19.0;
+    // launches: uint8 ffn.value -2.4 us, uint8 ffn.key -1.0, binary16 +-0 (ingest-bound); below 5 tiles it costs 0.8 % of a step
+    constexpr bool IL = RING_INTERLEAVE && MT >= 5;
     auto xfrag = [&](int ks, int mt) {
         const int m = mt * 16 + c;
 #if RING_ABLATE & 4
@@ -311,8 +319,8 @@ __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 
 #pragma unroll
     for (int g = 0; g < 4; g++) {                      // group g: k-step g >> 1, m-tiles [first, first + count)
         const int ks = g >> 1, first = (g & 1) ? HA : 0, count = (g & 1) ? HB : HA;
-        if (g + 1 < 4) {
-            const int nks = (g + 1) >> 1, nfirst = ((g + 1) & 1) ? HA : 0, ncount = ((g + 1) & 1) ? HB : HA;
+        const int nks = (g + 1) >> 1, nfirst = ((g + 1) & 1) ? HA : 0, ncount = g + 1 < 4 ? (((g + 1) & 1) ? HB : HA) : 0;
+        if constexpr (!IL) {
 #pragma unroll
             for (int j = 0; j < ncount; j++) bq[(g + 1) & 1][j] = xfrag(nks, nfirst + j);
         }
@@ -332,6 +340,15 @@ __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 
                 acc[nt][first + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt][ks], bq[g & 1][j], acc[nt][first + j], 0, 0, 0);
 #endif
             }
+            if constexpr (IL) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (j < ncount) bq[(g + 1) & 1][j] = xfrag(nks, nfirst + j);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if constexpr (IL) {
+#pragma unroll
+            for (int jj = count; jj < ncount; jj++) bq[(g + 1) & 1][jj] = xfrag(nks, nfirst + jj);     // (the next group is the larger one)
         }
         __builtin_amdgcn_sched_barrier(0);
     }

@@ -1,6 +1,6 @@
 """Timeline of ONE ring-GEMM launch from in-kernel 100-MHz stamps (include/chirrup_amd.h: skinny_gemm_clock_probe): when the
 workgroups enter, start and end their main loops and finish their epilogues, against the launch's duration as events see it.
-    python tools/gemm_timeline.py <key|value|out> [rows] [C]"""
+    python tools/gemm_timeline.py <key|value|out|key8|value8> [rows] [C]"""
 import os
 import sys
 
@@ -13,9 +13,16 @@ shape = sys.argv[1] if len(sys.argv) > 1 else "key"
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 dev, NW = "cuda:0", 10
-N, K = {"key": (4 * C, C), "value": (C, 4 * C), "out": (C, C)}[shape]
+N, K = {"key": (4 * C, C), "value": (C, 4 * C), "out": (C, C), "key8": (4 * C, C), "value8": (C, 4 * C)}[shape]
 torch.manual_seed(0)
-W = [ops.tile_weight((torch.randn(N, K, device=dev) / K ** 0.5).half()) for _ in range(NW)]
+if shape.endswith("8"):        # uint8 (mm8) weights as the decode step launches them
+    W = [ops.tile_weight_u8(torch.randint(0, 256, (N, K), device=dev, dtype=torch.uint8)) for _ in range(NW)]
+    rx, mx = torch.rand(N, device=dev).half() / 64, torch.randn(N, device=dev).half() * 0.01
+    ry2, my2 = torch.rand(N, device=dev).half() / 16, torch.randn(N, device=dev).half() * 0.01
+    S = torch.zeros(M, 1, 3, device=dev)
+    xs2, S2 = torch.empty(M, N, device=dev, dtype=torch.float16), torch.empty(M, ops.mm8_tile_parts(N), 3, device=dev)
+else:
+    W = [ops.tile_weight((torch.randn(N, K, device=dev) / K ** 0.5).half()) for _ in range(NW)]
 x = torch.randn(M, K, device=dev).half()
 parts = torch.empty(8 * M * N, dtype=torch.float32, device=dev)
 halves = M >= 128
@@ -26,6 +33,10 @@ def one(w):
         ops.skinny_linear(x, w, act=1, splits=0, row_halves=halves)
     elif shape == "value":
         ops.skinny_linear_partial(x, w, 8, parts)
+    elif shape == "key8":
+        ops.mm8t_gemm_fused(x, w, N, rx, mx, S, act=1, nxt=(ry2, my2, xs2, S2), tiled=True)
+    elif shape == "value8":
+        ops.mm8t_gemm_partial(x, w, N, 8, parts, tiled=True)
     else:
         ops.skinny_linear_partial(x, w, 0, parts, row_halves=halves)
 
