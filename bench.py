@@ -65,6 +65,8 @@ def parse():
     p.add_argument("--split-tmix-min-t", type=int, default=None, help="tokens per sequence from which the time-mix core runs as row-parallel launches around a recurrence-only scan, A/B only")
     p.add_argument("--chain-min-rows", type=int, default=None, help="batch rows from which R/K/V and the LoRA chain share one launch, tuning only")
     p.add_argument("--no-chain", action="store_true", help="LoRA up-projections as a launch of their own instead of inside the R/K/V launch, A/B only")
+    p.add_argument("--mm8-pair-max-rows", type=int, default=None, help="row limit of the in-launch reduction of the mm8 ffn.key launch, tuning only")
+    p.add_argument("--no-mm8-pair", action="store_true", help="mm8 ffn.key at <= 64 rows through partials + mm8_reduce_rows instead of the in-launch reduction, A/B only")
     p.add_argument("--torch-commit", action="store_true", help="the sampled ids' table updates as torch ops instead of the commit kernel, A/B only")
     p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
@@ -582,6 +584,10 @@ def main():
         _ops.PAIR_REDUCE = False
     if a.no_chain:
         model.chain_tmix_gemms = False
+    if a.no_mm8_pair:
+        model.mm8_pair_key = False
+    elif a.mm8_pair_max_rows is not None:
+        model.mm8_pair_max_rows = a.mm8_pair_max_rows
     if a.chain_min_rows is not None:
         model.chain_min_rows = a.chain_min_rows
     if a.row_halves_min_rows is not None:

@@ -125,6 +125,7 @@ struct BatchStrides {
     int *counters;     // EPI_PAIR: one zero-initialised int per tile; the second arriver leaves it zero again
     unsigned long long *clock;   // diagnostic (skinny_gemm_clock_probe): per workgroup {shader-clock ticks, 100-MHz ticks} of the main loop
     unsigned long long *timeline;   // ... and, behind the pairs, 4 absolute 100-MHz stamps per workgroup: kernel entry, loop start, loop end, epilogue done
+    int min_lds;       // host side only: at least this much dynamic LDS per workgroup (EPI_PAIR with a small ring: one workgroup per CU)
     int row_halves;    // 1: two workgroups per tile and K-slice, rows [0, m0) and [m0, M) of x / y, m0 = 16 * MT of the launch
                        //    (gridDim.y = 2 x splits): twice the workgroups WITHOUT more partials -- W is streamed by both
                        //    (one HBM fetch when they run side by side on one XCD), and with half the x image per stage the
@@ -594,6 +595,38 @@ __device__ __forceinline__ void combine_store_mm8(const float *stage, const int 
     }
 }
 
+// ... for a uint8 product whose epilogue is store_staged_mm8 (corrections, relu^2, the next product's prologue): the last
+// arriver first makes its staged sums the sums of ALL slices (slice order, the others' by sc1 loads), then runs that epilogue
+template <int THREADS>
+__device__ __forceinline__ void combine_into_stage(float *stage, const int M, const int n_first, const Tile &t, const int own_slice, const int slices) {
+    const int tid = threadIdx.x;
+    const int c4 = tid & 31;
+    const int n = n_first + 4 * c4;
+    if (n >= t.Np) return;
+    constexpr int RP = THREADS / 32;
+    const __amdgpu_buffer_rsrc_t src = make_rsrc(t.part, (int64_t)slices * M * t.Np * 4);
+    for (int m0 = tid >> 5; m0 < M; m0 += RP * 2) {
+        f32x4 oth[2][kPairMaxSlices];
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices && k != own_slice)
+                    oth[u][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(src, ((k * M + m0 + u * RP) * t.Np + n) * 4, 0, 16));
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int m = m0 + u * RP;
+            if (m >= M) break;
+            const f32x4 own = *reinterpret_cast<const f32x4 *>(stage + m * kLd + 4 * c4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};            // 0 + slice 0 + slice 1 + ...: mm8_reduce_rows' order
+#pragma unroll
+            for (int k = 0; k < kPairMaxSlices; k++)
+                if (k < slices) v += (k == own_slice) ? own : oth[u][k];
+            *reinterpret_cast<f32x4 *>(stage + m * kLd + 4 * c4) = v;
+        }
+    }
+}
+
 // accumulators of the wave that owns staged columns col0 .. col0+31: acc[nt][mt][i] is m = 16 mt + c, n = col0 + 16 nt + 4q + i
 template <int MT>
 __device__ __forceinline__ void stage_acc(float *stage, const f32x4 (&acc)[2][MT], const int M, const int col0, const int c, const int q) {
@@ -729,7 +762,15 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // (no instruction: keeps the loads below the barrier)
-        if (*flag) combine_store<256>(stg, t.M, n_base, t, t.kslice, (int)gridDim.y);
+        if (*flag) {
+            if constexpr (W8) {                        // uint8 weights: the mm8 epilogue over the sums of all slices
+                combine_into_stage<256>(stg, t.M, n_base, t, t.kslice, (int)gridDim.y);
+                __syncthreads();                       // (flag is uniform over the workgroup's four compute waves)
+                store_staged_mm8<256>(stg, t.M, n_base, t, bs.q8);
+            } else {
+                combine_store<256>(stg, t.M, n_base, t, t.kslice, (int)gridDim.y);
+            }
+        }
     } else {
         store_staged<EPI, 256>(stg, t.M, n_base, t, t.kslice, M);
     }
@@ -1490,7 +1531,8 @@ template <bool W8, int EPI>
 int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, int k_slice, const f16 *X, int ldx, const void *W,
                 int64_t ldw, f16 *Y, int ldy, const f16 *bias, float *part, BatchStrides bs = BatchStrides{},
                 const GroupTable &gt = GroupTable{}) {
-    const size_t lds = lds_bytes(bn, MT, W8);
+    size_t lds = lds_bytes(bn, MT, W8);
+    if (lds < (size_t)bs.min_lds) lds = (size_t)bs.min_lds;
     // tile_of_block deals contiguous runs of tiles to the XCDs only when the workgroup count divides by 8: round the
     // N-group count up (the extra workgroups leave at once)
     while ((grid.x * grid.y * grid.z) & 7) grid.x++;
@@ -1509,7 +1551,7 @@ int launch_gemm(int bn, int MT, dim3 grid, hipStream_t st, int M, int N, int K, 
         (void)hipGetDevice(&dev_);                                                                                        \
         if (!lds_limit_raised[dev_ & 31].load(std::memory_order_acquire)) {                                               \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                      (int)lds);                                                                          \
+                                      160 * 1024);                                                                        \
             lds_limit_raised[dev_ & 31].store(true, std::memory_order_release);                                           \
         }                                                                                                                 \
         hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, M, N, K, k_slice, X, ldx, W, ldw, Y, ldy, bias, part, bs, gt); \
@@ -2175,6 +2217,44 @@ extern "C" int mm8t_gemm_fused(int B, int N_in, int M_out, const void *xs, int x
     return launch_gemm<true, EPI_MM8>(bn, tiles_of(B, halves), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in,
                                       static_cast<const f16 *>(xs), xs_stride, wT, w_stride, static_cast<f16 *>(y), y ? y_stride : M_out,
                                       nullptr, nullptr, bs);
+}
+
+// mm8t_gemm_fused for few rows: the product is split `splits` ways over K (2..4; 0 = the library's choice) and the LAST of a
+// tile's workgroups to finish adds the other slices' sums to its own (slice order) and runs the same epilogue -- no partials for a
+// consumer, no mm8_reduce_rows launch.  partials: room for splits x B x M_out binary32 values (the slices' hand-off slabs);
+// tile_counters: as skinny_gemm_f16 (skinny_gemm_pair_counters() ints, zero before first use).  Limits: B <= 64 and
+// (splits - 1) * B <= 96; returns CHIRRUP_E_UNSUPPORTED where the in-launch reduction does not apply (callers then use
+// mm8t_gemm_partial + mm8_reduce_rows).  The sums are those of mm8_reduce_rows at the same split count, bit for bit.
+constexpr int kPairMaxRowsMm8 = 64;
+extern "C" int mm8t_gemm_fused_split(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride, int w_tiled,
+                                     const void *rx, const void *mx, const float *S, int S_parts, int act, void *y, int y_stride,
+                                     const void *ry2, const void *my2, void *xs2, float *S2, int splits, float *partials,
+                                     void *tile_counters, void *stream) {
+    if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    if (B <= 0 || B > 256 || N_in <= 0 || M_out <= 0 || (M_out & 7) || (N_in % kKB) || xs_stride < N_in || w_stride < N_in ||
+        (xs_stride & 7) || (w_stride & 15) || S_parts <= 0 || (y && (y_stride < M_out || (y_stride & 7))))
+        return CHIRRUP_E_SHAPE;
+    if (!xs || !wT || !rx || !mx || !S || (!y && !xs2) || !partials || !tile_counters) return CHIRRUP_E_NULL;
+    if (xs2 && (!ry2 || !my2 || !S2)) return CHIRRUP_E_NULL;
+    if (mis16(xs) || mis16(wT) || mis16(y) || mis16(xs2) || mis16(rx) || mis16(mx) || mis16(ry2) || mis16(my2) || mis16(partials) ||
+        (reinterpret_cast<uintptr_t>(tile_counters) & 3))
+        return CHIRRUP_E_ALIGN;
+    const int bn = choose_bn(M_out);
+    if (bn != 128) return CHIRRUP_E_UNSUPPORTED;
+    const int s = pick_splits(bn, M_out, N_in, splits);
+    const int tiles = (M_out + bn - 1) / bn;
+    if (s < 2 || s > kPairMaxSlices || (s - 1) * B > 96 || B > kPairMaxRowsMm8 || tiles + 8 > kPairCounters) return CHIRRUP_E_UNSUPPORTED;
+    const dim3 grid(tiles, s);
+    BatchStrides bs{};
+    bs.tiled = w_tiled ? 1 : 0;
+    bs.counters = static_cast<int *>(tile_counters);
+    bs.min_lds = 81 * 1024;                            // the fence-free hand-off is the one-workgroup-per-CU form (use_pair): the uint8 ring alone is 72 KiB at <= 32 rows
+    bs.q8.rx = static_cast<const f16 *>(rx), bs.q8.mx = static_cast<const f16 *>(mx), bs.q8.S = S, bs.q8.S_parts = S_parts;
+    bs.q8.ry2 = static_cast<const f16 *>(ry2), bs.q8.my2 = static_cast<const f16 *>(my2), bs.q8.xs2 = static_cast<f16 *>(xs2);
+    bs.q8.S2 = S2, bs.q8.S2_parts = mm8_tile_parts(M_out), bs.q8.act = act ? 1 : 0;
+    return launch_gemm<true, EPI_PAIR>(bn, tiles_of(B, false), grid, static_cast<hipStream_t>(stream), B, M_out, N_in, N_in / s,
+                                       static_cast<const f16 *>(xs), xs_stride, wT, w_stride, static_cast<f16 *>(y), y ? y_stride : M_out,
+                                       nullptr, partials, bs);
 }
 
 // Row-wise reduce of an mm8 product's partials with its rank-1 corrections (+ relu^2 when act = 1), writing y (may be

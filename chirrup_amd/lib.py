@@ -44,6 +44,7 @@ SIGNATURES = {
     "rwkv7_add_ln_mix_mm8": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _vp]),
     "mm8_tile_parts": (_i, [_i]),
     "mm8t_gemm_fused": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mm8t_gemm_fused_split": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "mm8t_gemm_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),
     "mm8_reduce_rows": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mm8_row_parts": (_i, [_i]),

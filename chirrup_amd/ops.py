@@ -817,10 +817,22 @@ def mm8_tile_parts(M: int) -> int:
     return _lib.load().mm8_tile_parts(M)
 
 
-def mm8t_gemm_fused(xs, wT, M_out: int, rx, mx, S, act: int = 0, y=None, nxt=None, tiled: bool = False, row_halves: bool = True):
-    """mm8t_gemm_partial + mm8_reduce_rows in one unsplit launch (include/chirrup_amd.h): xs [B<=256, N_in] fp16 (an mm8
+MM8_PAIR_MAX_ROWS = 64     # mm8t_gemm_fused(splits=...): the in-launch reduction's row limit (include/chirrup_amd.h: mm8t_gemm_fused_split)
+
+
+def mm8_fused_split_ok(B: int, N_in: int, M_out: int, splits: int = 0) -> bool:
+    """Whether mm8t_gemm_fused(..., splits=splits, partials=...) applies: few rows, a 2..4-way K split, slabs small enough."""
+    s = gemm_splits(M_out, N_in, 1, splits)
+    return PAIR_REDUCE and B <= MM8_PAIR_MAX_ROWS and 2 <= s <= 4 and (s - 1) * B <= 96 and M_out % 128 == 0 and M_out < 32768
+
+
+def mm8t_gemm_fused(xs, wT, M_out: int, rx, mx, S, act: int = 0, y=None, nxt=None, tiled: bool = False, row_halves: bool = True,
+                    splits=None, partials=None):
+    """mm8t_gemm_partial + mm8_reduce_rows in one launch (include/chirrup_amd.h): xs [B<=256, N_in] fp16 (an mm8
     prologue's output) with its row sums S [B, 3] or [B, parts, 3]; writes y [B, M_out] if given and, with
-    nxt = (ry2, my2, xs2 [B, M_out], S2 [B, mm8_tile_parts(M_out), 3]), the prologue of the next mm8 product."""
+    nxt = (ry2, my2, xs2 [B, M_out], S2 [B, mm8_tile_parts(M_out), 3]), the prologue of the next mm8 product.
+    Unsplit by default; splits (0 = the library's choice) with partials (fp32, room for [splits, B, M_out]): split over K and reduced
+    inside the launch by each tile's last workgroup (few rows only: mm8_fused_split_ok)."""
     B, N = xs.shape
     if not xs.is_cuda or xs.dtype != torch.float16 or xs.stride(1) != 1:
         raise _lib.ChirrupAmdError("xs: expected GPU fp16 with unit inner stride")
@@ -837,6 +849,20 @@ def mm8t_gemm_fused(xs, wT, M_out: int, rx, mx, S, act: int = 0, y=None, nxt=Non
         _chk(S2, "S2", torch.float32, (B, mm8_tile_parts(M_out), 3))
     if y is not None:
         _chk16("y", y, B * M_out)
+    if splits is not None:
+        if partials is None or partials.dtype != torch.float32 or not partials.is_contiguous() or not partials.is_cuda:
+            raise _lib.ChirrupAmdError("partials: expected contiguous GPU fp32")
+        s_used = gemm_splits(M_out, N, 1, splits)
+        if partials.numel() < s_used * B * M_out:
+            raise _lib.ChirrupAmdError("partials buffer too small")
+        counters = _tile_counters(xs.device)
+        if counters is None:
+            raise _lib.ChirrupAmdError("mm8t_gemm_fused(splits=...): the in-launch reduction is switched off (ops.PAIR_REDUCE)")
+        rc = _lib.load().mm8t_gemm_fused_split(B, N, M_out, xs.data_ptr(), xs.stride(0), wT.data_ptr(), N, int(tiled), rx.data_ptr(),
+                                               mx.data_ptr(), S.data_ptr(), S.numel() // (B * 3), act, _ptr(y), M_out, _ptr(ry2), _ptr(my2),
+                                               _ptr(xs2), _ptr(S2), splits, partials.data_ptr(), counters.data_ptr(), _stream())
+        _check_gemm(rc, "mm8t_gemm_fused_split", xs.device)
+        return
     rc = _lib.load().mm8t_gemm_fused(B, N, M_out, xs.data_ptr(), xs.stride(0), wT.data_ptr(), N, int(tiled), rx.data_ptr(), mx.data_ptr(),
                                      S.data_ptr(), S.numel() // (B * 3), act, _ptr(y), M_out, _ptr(ry2), _ptr(my2), _ptr(xs2), _ptr(S2),
                                      1 if row_halves else 0, _stream())

@@ -263,6 +263,9 @@ class RWKV_x070:
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
         self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
+        self.mm8_pair_key = True                         # ... and at few rows: the K split reduced inside the launch, the same epilogue (no mm8_reduce_rows launch)
+        self.mm8_pair_max_rows = 16                      # A/B on one box (profiles/r03_mm8_pair_key.txt): 7.2B bsz 8 3.11 -> 3.07 ms; bsz 32 3.37 -> 3.38, 1.5B bsz 32 1.687 -> 1.70,
+                                                         # 13.3B bsz 64 +-0 -- the last arriver's epilogue costs what the reduce launch cost
         self.split_rows_min = 1024                       # library GEMMs from this many rows: ffn.key as two row halves, R/K/V as three launches
         self.lora_per_problem = True                     # above 256 rows: one library GEMM per LoRA at its own rank, bias in the epilogue
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
@@ -590,8 +593,11 @@ class RWKV_x070:
             xs_k, S_k = new(rows, C), torch.empty((rows, 3), **f32)
             # ffn.key's corrections + relu^2 + ffn.value's prologue in the key GEMM's epilogue (unsplit launch, row halves)
             key_fused = self.mm8_fused_key and rows >= self.row_halves_min_rows and 4 * C < 32768
+            # few rows: the key product split over K and reduced by each tile's last workgroup, with the same epilogue -- no reduce launch
+            key_pair = (self.mm8_fused_key and self.mm8_pair_key and rows <= self.mm8_pair_max_rows and not key_fused and self._layers[0].f8_tiled
+                        and ops.mm8_fused_split_ok(rows, C, 4 * C, gs["ffn_key"]))
             xs_v = new(rows, 4 * C)
-            S_v = torch.empty((rows, ops.mm8_tile_parts(4 * C) if key_fused else ops.mm8_row_parts(4 * C), 3), **f32)
+            S_v = torch.empty((rows, ops.mm8_tile_parts(4 * C) if (key_fused or key_pair) else ops.mm8_row_parts(4 * C), 3), **f32)
             pbuf_k = None if key_fused else torch.empty((ops.gemm_splits(4 * C, C, 1, gs["ffn_key"]), rows, 4 * C), **f32)
             pbuf = torch.empty((ops.gemm_splits(C, 4 * C, 1, gs["ffn_value"]), rows, C), **f32)
 
@@ -762,6 +768,9 @@ class RWKV_x070:
                 if key_fused:
                     ops.mm8t_gemm_fused(xs_k, lw.f_K8.qT, 4 * C, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v),
                                         tiled=lw.f8_tiled)
+                elif key_pair:
+                    ops.mm8t_gemm_fused(xs_k, lw.f_K8.qT, 4 * C, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v),
+                                        tiled=lw.f8_tiled, splits=gs["ffn_key"], partials=pbuf_k)
                 else:
                     kparts = ops.mm8t_gemm_partial(xs_k, lw.f_K8.qT, 4 * C, gs["ffn_key"], pbuf_k, tiled=lw.f8_tiled, row_halves=rh["ffn_key"])
                     ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))

@@ -442,6 +442,16 @@ int mm8_tile_parts(int M_out);
 int mm8t_gemm_fused(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride, int w_tiled,
                     const void *rx, const void *mx, const float *S, int S_parts, int act, void *y, int y_stride,
                     const void *ry2, const void *my2, void *xs2, float *S2, int row_halves, void *stream);
+/* mm8t_gemm_fused for few rows: the product is split `splits` ways over K (2..4; 0 = the library's choice) and the last of a tile's
+ * workgroups to finish adds the other slices' sums to its own, in slice order, and runs the same epilogue -- no partials for a
+ * consumer and no mm8_reduce_rows launch.  partials: room for splits x B x M_out binary32 values (hand-off slabs); tile_counters: as
+ * skinny_gemm_f16.  B <= 64 and (splits - 1) * B <= 96, else CHIRRUP_E_UNSUPPORTED (use mm8t_gemm_partial + mm8_reduce_rows).
+ * Same sums as mm8_reduce_rows over mm8t_gemm_partial at the same split count, bit for bit; S2 has mm8_tile_parts(M_out) parts per row
+ * (as mm8t_gemm_fused), not mm8_row_parts. */
+int mm8t_gemm_fused_split(int B, int N_in, int M_out, const void *xs, int xs_stride, const void *wT, int64_t w_stride, int w_tiled,
+                          const void *rx, const void *mx, const float *S, int S_parts, int act, void *y, int y_stride,
+                          const void *ry2, const void *my2, void *xs2, float *S2, int splits, float *partials,
+                          void *tile_counters, void *stream);
 
 #ifdef __cplusplus
 }

@@ -568,3 +568,54 @@ def test_time_mix_launch_with_uint8_main_tiles(M, C, halves):
             assert float((rkv[j].float() - want[j].float()).abs().max()) <= 2e-3 * max(1.0, scale), (it, j)
         for j in range(4):
             assert bool(((up[j].double() - ref_up[j]).abs() <= 4e-3 * ref_up[j].abs().clamp_min(1.0)).all()), (it, j)
+
+
+@pytest.mark.parametrize("B,K,N,splits,tiled", [(32, 2048, 8192, 0, True), (64, 4096, 4096, 2, True), (17, 1024, 1024, 4, False), (1, 512, 384, 2, False),
+                                                 (48, 2048, 2048, 3, True), (24, 4096, 16384, 0, True)])
+def test_mm8_fused_epilogue_behind_the_in_launch_reduction(B, K, N, splits, tiled):
+    """mm8t_gemm_fused(splits=..., partials=...) at <= 64 rows: the product split over K, each tile's last workgroup adds the other
+    slices' sums in slice order and runs the EPI_MM8 epilogue.  Same core sums as mm8t_gemm_partial at that split count reduced by
+    mm8_reduce_rows: y and the next product's xs bit-identical, its row sums (per 128-column tile instead of per 1024 columns) equal in
+    binary64 terms; repeated launches reproduce themselves and leave the tile counters at zero; where the in-launch reduction does not
+    apply the wrapper's predicate says so."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(B + K + N)
+    dev = "cuda"
+    x = torch.randn(B, K, device=dev).half()
+    q = torch.randint(0, 256, (N, K), device=dev, dtype=torch.uint8)
+    mx, rx = torch.randn(N, device=dev).half() * 0.01, torch.rand(N, device=dev).half() / 64
+    my, ry = torch.randn(K, device=dev).half() * 0.01, torch.rand(K, device=dev).half() / 16
+    my2, ry2 = torch.randn(N, device=dev).half() * 0.01, torch.rand(N, device=dev).half() / 16
+    xs = (x.float() * ry.float()).half()
+    S = torch.stack([xs.float().sum(1), (x.float() * my.float()).sum(1), x.float().sum(1)], 1).contiguous()
+    tiled = tiled and N % 128 == 0
+    qT = ops.tile_weight_u8(q) if tiled else q
+    ok = ops.mm8_fused_split_ok(B, K, N, splits)
+    s_used = ops.gemm_splits(N, K, 1, splits)
+    if not ok:
+        assert N % 128 or not (2 <= s_used <= 4) or (s_used - 1) * B > 96
+        return
+    parts = ops.mm8t_gemm_partial(xs, qT, N, splits, torch.empty(s_used, B, N, device=dev), tiled=tiled)
+    assert parts.shape[0] == s_used
+    y_a, xs_a = torch.empty(B, N, device=dev, dtype=torch.float16), torch.empty(B, N, device=dev, dtype=torch.float16)
+    S_a = torch.empty(B, ops.mm8_row_parts(N), 3, device=dev)
+    ops.mm8_reduce_rows(parts, rx, mx, S, act=1, y=y_a, nxt=(ry2, my2, xs_a, S_a))
+    slabs = torch.empty(s_used, B, N, device=dev)
+    for it in range(4):
+        y_b = torch.full((B, N), float("nan"), device=dev, dtype=torch.float16)
+        xs_b = torch.full((B, N), float("nan"), device=dev, dtype=torch.float16)
+        S_b = torch.full((B, ops.mm8_tile_parts(N), 3), float("nan"), device=dev)
+        slabs.fill_(float("nan"))
+        ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=1, y=y_b, nxt=(ry2, my2, xs_b, S_b), tiled=tiled, splits=splits, partials=slabs)
+        torch.cuda.synchronize()
+        assert torch.equal(y_a, y_b) and torch.equal(xs_a, xs_b), it
+        want = torch.stack([xs_a.double().sum(1), (y_a.double() * my2.double()).sum(1), y_a.double().sum(1)], 1)
+        scale = torch.stack([xs_a.double().abs().sum(1), (y_a.double() * my2.double()).abs().sum(1), y_a.double().abs().sum(1)], 1) + 1e-30
+        assert float(((S_b.double().sum(1) - want).abs() / scale).max()) < 1e-5
+        assert int(ops._tile_counters(x.device).abs().sum()) == 0
+    # y only, no relu^2
+    y_c, y_d = torch.empty(B, N, device=dev, dtype=torch.float16), torch.empty(B, N, device=dev, dtype=torch.float16)
+    ops.mm8_reduce_rows(parts, rx, mx, S, act=0, y=y_c)
+    ops.mm8t_gemm_fused(xs, qT, N, rx, mx, S, act=0, y=y_d, tiled=tiled, splits=splits, partials=slabs)
+    assert torch.equal(y_c, y_d)
