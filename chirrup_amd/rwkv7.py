@@ -943,11 +943,20 @@ class SlotDecodeGraph:
         self._stage = [[torch.zeros((B, 1), dtype=torch.long).pin_memory(), torch.zeros((B,), dtype=torch.int32).pin_memory(), None]
                        for _ in range(2)]
         self._runs = 0
+        self._last_inputs = None
 
     def run(self, tokens: Sequence[int], slots: Sequence[int]) -> torch.Tensor:
         """tokens[i] goes to slot slots[i]; returns the static logits tensor, rows [0, len(slots)) valid."""
         n = len(slots)
         assert n <= self.B and len(tokens) == n
+        # steady-state decode: every row feeds back its own last id (-1) and the slot list has not changed -- the static buffers
+        # already hold exactly this, and two host-to-device copies (with their ~80 us of copy-engine hand-over in front of the graph)
+        # are skipped
+        key = (tuple(tokens), tuple(slots))
+        if key == self._last_inputs:
+            self.graph.replay()
+            return self.logits
+        self._last_inputs = key if all(t < 0 for t in tokens) else None      # (explicit token ids are consumed: never "unchanged")
         st = self._stage[self._runs & 1]
         self._runs += 1
         tok_host, idx_host, copied = st

@@ -91,6 +91,8 @@ class Worker:
         self.max_prefill_count = max(int(batch_size * 0.125), 1)
         self.state_slot: Dict[int, dict] = {i: _empty_slot() for i in range(self.max_batch_size)}
         self.model, self.tokenizer = model, tokenizer   # may be injected (tests use a fake backend)
+        self._slot_cache: Dict[tuple, torch.Tensor] = {}
+        self._max_mem_gb = None
         self._penalize_argmax = penalize_argmax if penalize_argmax is not None else ops.penalize_argmax
         self._sample_topp = ops.sample_topp if penalize_argmax is None else None     # fake backends use the torch sampler
         self._commit_kernel = ops.commit_sampled if penalize_argmax is None else None  # ... and torch ops for the commit
@@ -369,7 +371,17 @@ class Worker:
 
     # ------------------------------------------------------------------ device dispatch
     def _slot_tensor(self, slots: List[int]) -> torch.Tensor:
-        return torch.tensor(slots, dtype=torch.int32, device=self.device)
+        """Device copy of a list of slot / row ids, cached: torch.tensor(list, device=...) is a pageable host-to-device copy, i.e.
+        the host blocks until everything already enqueued on the stream has run -- once per iteration that turned the run-ahead loop into
+        a lock-step one (the GPU idled ~200 us per 7-ms iteration while the host enqueued the next).  The decode slot list is the same
+        from one iteration to the next until a request arrives or leaves; the tensors are never written."""
+        key = tuple(slots)
+        t = self._slot_cache.get(key)
+        if t is None:
+            if len(self._slot_cache) >= 16:
+                self._slot_cache.pop(next(iter(self._slot_cache)))
+            t = self._slot_cache[key] = torch.tensor(slots, dtype=torch.int32, device=self.device)
+        return t
 
     def _run_forward_one(self, decode_slots: List[int], prefill_slots: List[int]):
         """Enqueue one forward + sampling for these slots; returns the record `_handle_results` consumes."""
@@ -383,7 +395,7 @@ class Worker:
         sampled = [j for j, s in enumerate(decode_slots) if not self._greedy[s]]
         rows = u = None
         if sampled:
-            rows = torch.tensor(sampled, device=self.device, dtype=torch.int32)
+            rows = self._slot_tensor(sampled)
             u = torch.rand((len(sampled),), device=self.device, dtype=torch.float32)
         tokens = []
         for j, s in enumerate(slots):
@@ -525,11 +537,13 @@ class Worker:
             if ops.chain_status():
                 raise RuntimeError("a time-mix launch gave up waiting for its own workgroups (status word set): results are undefined")
         self.loop_time_recorder.append(time.perf_counter() - t0)
+        if (self.iterations & 63) == 1 or self._max_mem_gb is None:      # (memory_stats() walks a dictionary of ~150 counters: 0.12 ms per call)
+            self._max_mem_gb = (torch.cuda.max_memory_allocated() / 1024 ** 3) if torch.cuda.is_available() else 0.0
         self._post({"avg_loop_time": sum(self.loop_time_recorder) / len(self.loop_time_recorder),
                     "state_size": self.real_state_size,
                     "state_offset_details": {"decode_slots": dec, "one_prefill_slots": pre, "seq_prefill_slots": seq},
                     "task_details": {"decode_count": len(dec), "one_prefill_count": len(pre), "seq_prefill_count": len(seq)},
-                    "max_allocated_memory_GB": (torch.cuda.max_memory_allocated() / 1024 ** 3) if torch.cuda.is_available() else 0.0},
+                    "max_allocated_memory_GB": self._max_mem_gb},
                    "worker_performance")
         return True
 
