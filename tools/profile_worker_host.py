@@ -1,5 +1,5 @@
 """Host side of the Worker loop under cProfile: where the Python time of an iteration goes (200 concurrent greedy requests on a small
-model so that the GPU is not the limit).  usage: python tools/profile_worker_host.py [model=0.4B] [n_requests=200] [iterations=200]"""
+model so that the GPU is not the limit).  usage: python tools/profile_worker_host.py [model=0.4B] [n_requests=200] [iterations=200] [mode=0|2]"""
 import cProfile
 import os
 import pstats
@@ -18,6 +18,7 @@ from chirrup_amd.worker import Worker
 name = sys.argv[1] if len(sys.argv) > 1 else "0.4B"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0      # 0 greedy; 2 the reference's default sampling config (T = 1, top_p = 0.3, penalties)
 L, C = CONFIGS[name]
 dev = torch.device("cuda", 0)
 model = RWKV_x070(model_args("synthetic"), state_dict=make_state_dict(L, C, 65536, seed=42, device=dev), device=dev)
@@ -44,7 +45,8 @@ w._init_worker()
 g = torch.Generator().manual_seed(1234)
 for i in range(N):
     tq.put(Task(output_queue=Sink(), task_event_queue=queue.Queue(), prompt_str="", prefill_tokens=torch.randint(1, 65536, (4,), generator=g).tolist(),
-                state=None, temperature=0.0, top_p=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=0.996, stop_tokens=[],
+                state=None, temperature=1.0 if mode else 0.0, top_p=0.3 if mode else 0.0, frequency_penalty=0.5 if mode else 0.0,
+                presence_penalty=0.5 if mode else 0.0, penalty_decay=0.996, stop_tokens=[],
                 max_tokens=iters + 50))
 for _ in range(10):
     w.step()

@@ -26,7 +26,7 @@ print("per iteration over %d iterations: span %.1f us, kernels busy %.1f us, idl
 for k in sorted(acc, key=lambda k: -acc[k]):
     print("  %7.1f us  x%5.1f  %s" % (acc[k] / n, cnt[k] / n, k))
 gaps = collections.defaultdict(float)
-short = lambda nm: next((o for o in ours if o in nm), nm.split("<")[0].split("(")[0][-40:])
+short = lambda nm: next((o for o in ours if o in nm), nm[:90])
 for (s0, e0, n0), (s1, e1, n1) in zip(seg, seg[1:]):
     if s1 - e0 > 500:
         gaps[short(n0) + "  ->  " + short(n1)] += (s1 - e0) / 1e3
