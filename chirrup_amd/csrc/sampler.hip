@@ -213,76 +213,64 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
         for (int e = 0; e < 8; e++) mx = fmaxf(mx, (float)v[e]);
     }
     mx = block_reduce_max(mx, red);
+    // this lane's elements -- the token pairs {2 (tid + 1024 i), +1} -- as un-normalised mass in registers; their 16-bit
+    // order-preserving keys are re-derived from the row in LDS in every pass (two per 4-byte read; 64 masses AND 64 keys do not fit
+    // the 128 registers a lane of a 1024-lane workgroup has)
+    constexpr int kPairs = 65536 / kSampThreads / 2;
+    typedef f16 f16x2_t __attribute__((ext_vector_type(2)));
+    float ms[2 * kPairs];
     float z = 0.f;
-    for (int c = tid; c < V; c += kSampThreads) z += __expf((float)row[c] - mx);
+#pragma unroll
+    for (int i = 0; i < kPairs; i++) {
+        const int c = 2 * (tid + i * kSampThreads);
+        float m0 = 0.f, m1 = 0.f;
+        if (c < V) {                                 // (V is even: checked by the entry point)
+            const f16x2_t v = *reinterpret_cast<const f16x2_t *>(row + c);
+            m0 = __expf((float)v[0] - mx), m1 = __expf((float)v[1] - mx);
+        }
+        ms[2 * i] = m0, ms[2 * i + 1] = m1;
+        z += m0 + m1;
+    }
     const float Z0 = block_reduce_sum(z, red);
     const float target = P * Z0;                 // in un-normalised mass
 
-    // ---- two-level radix search: largest key c_key with mass{key >= c_key} >= target,
-    //      and (top-k) largest key k_key with count{key >= k_key} >= K
-    unsigned prefix = 0;            // high byte once level 0 is done
+    // ---- the cutoffs, by bisection over the key bits: c_key = the largest key with mass{key >= c_key} >= target, k_key = the
+    //      largest key with count{key >= k_key} >= K (top-k).  16 passes, one block reduction each.  (Rounds 1-2 built two-level
+    //      histograms in LDS with atomics: with real logits most tokens fall into a few bins, the same-address atomics serialise,
+    //      and the kernel took 167 us for 200 rows.)
     unsigned c_key = 0, k_key = 0;
-    float mass_above = 0.f;         // mass strictly above the current search window
-    unsigned cnt_above = 0;
-    bool p_done = false, k_done = (Kk <= 0);
-    unsigned p_hi = 0, k_hi = 0;
-    float p_mass_above = 0.f;
-    unsigned k_cnt_above = 0;
-    for (int level = 0; level < 2; level++) {
-        // level 1 may need two different high bytes (one for top-p, one for top-k): run it per criterion
-        for (int crit = 0; crit < (level == 0 ? 1 : 2); crit++) {
-            if (level == 1) {
-                if (crit == 0 && p_done) continue;
-                if (crit == 1 && k_done) continue;
-                prefix = crit == 0 ? p_hi : k_hi;
-                mass_above = p_mass_above;
-                cnt_above = k_cnt_above;
+    const bool use_k = Kk > 0;
+    unsigned *redu = hcnt;                       // [16]
+    for (int bit = 15; bit >= 0; bit--) {
+        const unsigned cp = c_key | (1u << bit), ck = k_key | (1u << bit);
+        float m = 0.f;
+        unsigned n = 0;                              // low half: tokens with key >= ck (top-k); high half: ... with key >= cp
+#pragma unroll
+        for (int i = 0; i < kPairs; i++) {
+            const int c = 2 * (tid + i * kSampThreads);
+            if (c < V) {
+                const f16x2_t v = *reinterpret_cast<const f16x2_t *>(row + c);
+                const unsigned k0 = key_of(v[0]), k1 = key_of(v[1]);
+                m += (k0 >= cp ? ms[2 * i] : 0.f) + (k1 >= cp ? ms[2 * i + 1] : 0.f);
+                n += (k0 >= cp ? 0x10000u : 0u) + (k1 >= cp ? 0x10000u : 0u);
+                if (use_k) n += (k0 >= ck ? 1u : 0u) + (k1 >= ck ? 1u : 0u);
             }
-            for (int i = tid; i < kHistReplicas * 256; i += kSampThreads) { hmass[i] = 0.f; hcnt[i] = 0u; }
-            __syncthreads();
-            const int rep = (tid >> 6) & (kHistReplicas - 1);
-            for (int c = tid; c < V; c += kSampThreads) {
-                const unsigned k16 = key_of(row[c]);
-                if (level == 1 && (k16 >> 8) != prefix) continue;
-                const unsigned bin = level == 0 ? (k16 >> 8) : (k16 & 255u);
-                atomicAdd(&hmass[rep * 256 + bin], __expf((float)row[c] - mx));
-                atomicAdd(&hcnt[rep * 256 + bin], 1u);
-            }
-            __syncthreads();
-            if (tid < 256) {
-                float m = 0.f; unsigned n = 0;
-                for (int q = 0; q < kHistReplicas; q++) { m += hmass[q * 256 + tid]; n += hcnt[q * 256 + tid]; }
-                hmass[tid] = m; hcnt[tid] = n;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                // walk from the largest bin down
-                if (level == 0 || crit == 0) {
-                    if (!p_done) {
-                        float acc = mass_above; int b = 255; bool hit = false;
-                        for (; b >= 0; b--) { if (acc + hmass[b] >= target && hcnt[b] > 0) { hit = true; break; } acc += hmass[b]; }
-                        scal[0] = hit ? (float)b : -1.f; scal[1] = acc;
-                    }
-                }
-                if (level == 0 || crit == 1) {
-                    if (!k_done) {
-                        unsigned acc = cnt_above; int b = 255; bool hit = false;
-                        for (; b >= 0; b--) { if (acc + hcnt[b] >= (unsigned)Kk && hcnt[b] > 0) { hit = true; break; } acc += hcnt[b]; }
-                        scal[2] = hit ? (float)b : -1.f; scal[3] = (float)acc;
-                    }
-                }
-            }
-            __syncthreads();
-            if (level == 0) {
-                if (!p_done) { if (scal[0] < 0.f) { c_key = 0; p_done = true; } else { p_hi = (unsigned)scal[0]; p_mass_above = scal[1]; } }
-                if (!k_done) { if (scal[2] < 0.f) { k_key = 0; k_done = true; } else { k_hi = (unsigned)scal[2]; k_cnt_above = (unsigned)scal[3]; } }
-            } else if (crit == 0) {
-                c_key = scal[0] < 0.f ? (p_hi << 8) : ((p_hi << 8) | (unsigned)scal[0]);
-            } else {
-                k_key = scal[2] < 0.f ? (k_hi << 8) : ((k_hi << 8) | (unsigned)scal[2]);
-            }
-            __syncthreads();
         }
+        const unsigned any_p = __any((n >> 16) != 0);        // (a count of 65536 would overflow the half: only "any" is asked of it)
+        n &= 0xffffu;                                          // per lane at most 64
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            m += __shfl_xor(m, o, 64);
+            n += __shfl_xor(n, o, 64);
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = m, redu[tid >> 6] = n | (any_p ? 0x80000000u : 0u);
+        __syncthreads();
+        float M = 0.f;
+        unsigned Nn = 0, anyp = 0;
+        for (int w = 0; w < kSampThreads / 64; w++) M += red[w], Nn += redu[w] & 0x7fffffffu, anyp |= redu[w] >> 31;
+        if (M >= target && anyp) c_key = cp;         // ... among the keys that occur (top_p = 0: the row's largest key, i.e. greedy)
+        if (use_k && Nn >= (unsigned)Kk) k_key = ck;
     }
     const unsigned thr = (Kk > 0 && k_key > c_key) ? k_key : c_key;
 
