@@ -85,7 +85,10 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                                        float (&out)[kLnMaxChunks][8], float *red, const float *__restrict__ dpart = nullptr,
                                        int dsplits = 0, int64_t dsplit_stride = 0, const f16 *__restrict__ q_rx = nullptr,
                                        const f16 *__restrict__ q_mx = nullptr, const float *__restrict__ q_S = nullptr,
-                                       const int q_parts = 0, float *q_sh = nullptr) {
+                                       const int q_parts = 0, float *q_sh = nullptr, unsigned long long *st = nullptr) {
+    auto stamp = [&](int i) {
+        if (st && threadIdx.x == 0) st[i] = __builtin_amdgcn_s_memrealtime();
+    };
     // q_S: this row's mm8 row sums [q_parts][3] in global memory; they are added up (one wave per sum) into q_sh[3] AFTER the
     // loads of the row and of its first four partial planes have been issued, so that their latency is not a stage of its own
     constexpr bool HOIST = TH < kLnMaxThreads;
@@ -162,7 +165,9 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
             }
         }
     }
+    stamp(1);                                          // lane 0's row data has arrived (its sums are formed)
     const float mean = block_sum<TH>(s, red) / (float)C;
+    stamp(2);
     float s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
@@ -176,6 +181,7 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
         }
     }
     const float rstd = 1.0f / sqrtf(block_sum<TH>(s2, red) / (float)C + eps);
+    stamp(3);
 #pragma unroll
     for (int q = 0; q < kLnMaxChunks; q++) {
         const int c = threadIdx.x + q * TH;
@@ -195,7 +201,12 @@ __global__ __launch_bounds__(TH) void add_ln_mix_kernel(
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
     const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride,
-    const chirrup_mm8_fuse fz, const int R) {
+    const chirrup_mm8_fuse fz, const int R, unsigned long long *stamps) {
+    // diagnostic (rwkv7_ln_probe; tools/ln_timeline.py): 100-MHz stamps of a workgroup's phases, 8 per workgroup
+    auto stamp = [&](int i) {
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
     constexpr bool HOIST = TH < kLnMaxThreads;
     __shared__ float red[3 * (TH / 64)];
     // A workgroup takes R consecutive tokens of one sequence: the token shift of row t needs LN(row t-1), which is the row
@@ -241,7 +252,9 @@ __global__ __launch_bounds__(TH) void add_ln_mix_kernel(
             for (int m = 0; m < NMIX; m++) mvh[m] = *reinterpret_cast<const f16x8 *>(mix + (int64_t)m * C + threadIdx.x * 8);
         }
         ln_row<TH>(x + ro, delta ? delta + ro : nullptr, x_out ? x_out + ro : nullptr, ln_w, ln_b, C, eps, cur, red,
-               dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0]);
+               dpart ? dpart + ro : nullptr, dsplits, dsplit_stride, q_rx, q_mx, q_row, fz.in_S_parts, qsum[0],
+               stamps ? stamps + (int64_t)blockIdx.x * 8 : nullptr);
+        stamp(4);                                      // normalised (the LN weights have arrived)
         if (NMIX == 0) {
 #pragma unroll
             for (int q = 0; q < kLnMaxChunks; q++) {
@@ -312,6 +325,11 @@ __global__ __launch_bounds__(TH) void add_ln_mix_kernel(
         for (int q = 0; q < kLnMaxChunks; q++)
 #pragma unroll
             for (int e = 0; e < 8; e++) prev[q][e] = cur[q][e];
+        stamp(5);                                      // lerps formed, stores issued
+    }
+    if (stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamps[(int64_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();      // lane 0's stores acknowledged
     }
 }
 
@@ -442,6 +460,14 @@ inline bool mis16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 }  // namespace
 
+// Diagnostic (tools/ln_timeline.py): while set, every add_ln_mix launch writes 8 100-MHz stamps per workgroup to buf (entry, row data
+// arrived, mean, variance, normalised, stores issued, stores acknowledged); buf must hold 8 x the largest grid.  Process-wide.
+static unsigned long long *g_ln_probe = nullptr;
+extern "C" int rwkv7_ln_probe(void *buf) {
+    g_ln_probe = static_cast<unsigned long long *>(buf);
+    return 0;
+}
+
 extern "C" int rwkv7_add_ln_mix(int B, int T, int C, int n_mix, const void *x, const void *delta, void *x_out,
                                 const void *ln_w, const void *ln_b, float eps, const void *prev_in, void *prev_out,
                                 const void *mix, void *out, int64_t out_stride, const int32_t *slot_idx,
@@ -491,7 +517,7 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
     const dim3 grid((unsigned)(B * ((T + R - 1) / R))), block(TH);
 #define ARGS T, C, (const f16 *)x, (const f16 *)delta, (f16 *)x_out, (const f16 *)ln_w, (const f16 *)ln_b, eps, \
              (const f16 *)prev_in, (f16 *)prev_out, (const f16 *)mix, (f16 *)out, out_stride, slot_idx, delta_partials, \
-             delta_splits, (int64_t)B * T * C, q, R
+             delta_splits, (int64_t)B * T * C, q, R, g_ln_probe
 #define LN_GO(NM)                                                                                  \
     do {                                                                                           \
         if (TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256>), grid, block, 0, st, ARGS);  \

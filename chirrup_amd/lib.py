@@ -72,6 +72,7 @@ SIGNATURES = {
     "skinny_gemm_clock_probe": (_i, [_vp, _i]),
     "skinny_gemm_warm_probe": (_i, [_i, _vp]),
     "chirrup_clock_probe": (_i, [_i, _vp, _vp]),
+    "rwkv7_ln_probe": (_i, [_vp]),
     "chirrup_noop_launch": (_i, [_i, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_grouped": (_i, [_i, _i, _i, _i, _vp, _vp, _i, _i64, _vp, _i64, _i64, _i, _vp, _i64, _vp, _i, _i64, _i, _i, _i, _vp, _vp]),
     "skinny_gemm_f16_partial": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp]),

@@ -300,6 +300,9 @@ int skinny_gemm_warm_probe(int stages, void *sink);
 /* The chip's clock without load: one wavefront spins `iters` dependent VALU operations; out (uint64 [2]) receives {shader-clock
  * ticks, 100-MHz ticks}. */
 int chirrup_clock_probe(int iters, void *out, void *stream);
+/* Diagnostic (tools/ln_timeline.py): while buf is set every rwkv7_add_ln_mix* launch writes 8 100-MHz stamps per workgroup
+ * (entry, row data arrived, mean, variance, normalised, stores issued, stores acknowledged, unused); NULL switches it off. */
+int rwkv7_ln_probe(void *buf);
 /* Launch-cost probe (tools/launch_cost.py): `grid` workgroups of `block` lanes that hold lds_bytes of LDS, idle for sleep x ~4 us
  * and do nothing else. */
 int chirrup_noop_launch(int grid, int block, int lds_bytes, int sleep, void *sink, void *stream);
