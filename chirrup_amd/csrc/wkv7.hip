@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const f16 *__restrict__ k_, const f16 *__restrict__ v_, const f16 *__restrict__ a_,
     const f16 *__restrict__ b_, f16 *__restrict__ y_, const int32_t *__restrict__ elapsed_t, const TmixArgs tm) {
     // [0, 8192): swizzled state image; then r, w~, k, a, b strips of 128 B each.
-    __shared__ __attribute__((aligned(16))) unsigned char smem[kStateBytes + 5 * kVecBytes];
+    // (the chunk scan -- MODE 0, DECAYED -- keeps TWO strips: token t + 1's vectors are written while token t's are read)
+    constexpr bool kTwoStrips = MODE == 0 && DECAYED;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kStateBytes + (kTwoStrips ? 10 : 5) * kVecBytes];
 
     const int bb = blockIdx.x / H;
     const int h = blockIdx.x - bb * H;
@@ -174,6 +176,68 @@ __global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const f16x2 *A2 = reinterpret_cast<const f16x2 *>(smem + kStateBytes + 3 * kVecBytes);
     const f16x2 *B2 = reinterpret_cast<const f16x2 *>(smem + kStateBytes + 4 * kVecBytes);
 
+    if constexpr (kTwoStrips) {
+        // The chunk scan with few sequences is ONE wave per SIMD, and a lone wave exposes every latency of the token's chain
+        // "vectors -> LDS strip -> broadcast reads -> two 32-long dependent sums" (1 x 256 tokens at 7.2B: 1.68 us per token, 65 % of the
+        // chunk).  Two strips: token t + 1's vectors (in registers since the iteration before) are written while token t's are read,
+        // and token t + 2's are requested -- the strip's write-to-read latency and the global loads leave the critical path.  Same
+        // arithmetic on the same values in the same order: bit-exact with the one-strip loop (tests/test_wkv7_gpu.py).
+        auto put = [&](int which, f16 r, f16 w, f16 k, f16 a, f16 b) {
+            f16 *v5 = vec + which * 5 * 64;
+            v5[0 * 64 + lane] = r, v5[1 * 64 + lane] = w, v5[2 * 64 + lane] = k, v5[3 * 64 + lane] = a, v5[4 * 64 + lane] = b;
+        };
+        put(0, rj, wj, kj, aj, bj);
+        f16 v_cur = vi;
+        f16 r1 = (f16)0.f, w1 = r1, k1 = r1, v1 = r1, a1 = r1, b1 = r1;      // token t + 1
+        if (T > 1) {
+            const int64_t o1 = o + C;
+            r1 = r_[o1], w1 = w_[o1], k1 = k_[o1], v1 = v_[o1], a1 = a_[o1], b1 = b_[o1];
+        }
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < T; t++) {
+            f16 r2 = (f16)0.f, w2 = r2, k2 = r2, v2 = r2, a2 = r2, b2 = r2;  // token t + 2: requested now, used next iteration
+            if (t + 2 < T) {
+                const int64_t o2 = o + 2 * (int64_t)C;
+                r2 = r_[o2], w2 = w_[o2], k2 = k_[o2], v2 = v_[o2], a2 = a_[o2], b2 = b_[o2];
+            }
+            // the whole strip of token t into registers in one burst of 40 reads (it was written an iteration ago: no store-to-load
+            // wait), pinned in front of the arithmetic -- left to itself the scheduler trickles the reads in between the packed ops
+            // with a counted wait in front of every group, and a lone wave pays each of those waits
+            f16x2 pR[32], pW[32], pK[32], pA[32], pB[32];
+            {
+                const f16x8 *P8 = reinterpret_cast<const f16x8 *>(smem + kStateBytes + (t & 1) * 5 * kVecBytes);
+                auto get = [&](f16x2 (&dst)[32], int which) {
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; c8++) {
+                        const f16x8 q8 = P8[which * 8 + c8];
+                        dst[4 * c8 + 0] = q8.s01, dst[4 * c8 + 1] = q8.s23, dst[4 * c8 + 2] = q8.s45, dst[4 * c8 + 3] = q8.s67;
+                    }
+                };
+                get(pA, 3), get(pW, 1), get(pK, 2), get(pB, 4), get(pR, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f16x2 sa2 = {(f16)0.f, (f16)0.f};
+#pragma unroll
+            for (int p = 0; p < 32; p++) sa2 = sa2 + pA[p] * S[p];
+            const f16 sa = sa2.x + sa2.y;
+            const f16x2 sab = {sa, sa};
+            const f16x2 vv2 = {v_cur, v_cur};
+            if (t + 1 < T) put((t + 1) & 1, r1, w1, k1, a1, b1);             // (the other strip: nobody reads it in this iteration)
+            f16x2 y2 = {(f16)0.f, (f16)0.f};
+#pragma unroll
+            for (int p = 0; p < 32; p++) {
+                f16x2 sv = S[p];
+                sv = sv + (sv * pW[p] + pK[p] * vv2 + sab * pB[p]);
+                S[p] = sv;
+                y2 = y2 + sv * pR[p];
+            }
+            y_[o] = y2.x + y2.y;
+            __builtin_amdgcn_s_barrier();          // single-wave workgroup: orders the strips, never waits
+            o += C;
+            v_cur = v1;
+            r1 = r2, w1 = w2, k1 = k2, v1 = v2, a1 = a2, b1 = b2;
+        }
+    } else
     for (int t = 0; t < T; t++) {
         // dither: int32 wrap-around multiply, int -> float, exact scale (.cu:23, :59)
         const float dither = kTwoToNeg41 * (float)(int32_t)(kRo1 * (uint32_t)(et + t));
