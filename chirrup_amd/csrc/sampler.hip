@@ -187,6 +187,71 @@ __device__ __forceinline__ float block_reduce_max(float v, float *red) {
     return t;
 }
 
+// One packed pair of keys d = klo | khi << 16 against three rising thresholds p1 < p2 < p3 (P = p << 16): m_i += mass of the keys
+// >= p_i.  v_cmpx narrows EXEC so that each (key, threshold) costs a compare and an add -- the compiler's own form is compare,
+// select, add, and a CU issues only 64 lanes of VALU per clock, which is what bounds the cutoff search.
+__device__ __forceinline__ void mass_ge3(unsigned d, float mlo, float mhi, unsigned p1, unsigned p2, unsigned p3, unsigned P1,
+                                         unsigned P2, unsigned P3, float &m1, float &m2, float &m3) {
+    unsigned t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_and_b32_e32 %[t], 0xffff, %[d]\n\t"
+        "v_cmpx_le_u32_e32 %[p1], %[t]\n\t"
+        "v_add_f32_e32 %[m1], %[m1], %[mlo]\n\t"
+        "v_cmpx_le_u32_e32 %[p2], %[t]\n\t"
+        "v_add_f32_e32 %[m2], %[m2], %[mlo]\n\t"
+        "v_cmpx_le_u32_e32 %[p3], %[t]\n\t"
+        "v_add_f32_e32 %[m3], %[m3], %[mlo]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_le_u32_e32 %[P1], %[d]\n\t"
+        "v_add_f32_e32 %[m1], %[m1], %[mhi]\n\t"
+        "v_cmpx_le_u32_e32 %[P2], %[d]\n\t"
+        "v_add_f32_e32 %[m2], %[m2], %[mhi]\n\t"
+        "v_cmpx_le_u32_e32 %[P3], %[d]\n\t"
+        "v_add_f32_e32 %[m3], %[m3], %[mhi]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m1] "+v"(m1), [m2] "+v"(m2), [m3] "+v"(m3), [t] "=&v"(t), [sv] "=&s"(sv)
+        : [d] "v"(d), [mlo] "v"(mlo), [mhi] "v"(mhi), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [P1] "s"(P1), [P2] "s"(P2), [P3] "s"(P3)
+        : "vcc");
+}
+// the same for counts
+__device__ __forceinline__ void count_ge3(unsigned d, unsigned p1, unsigned p2, unsigned p3, unsigned P1, unsigned P2, unsigned P3,
+                                          unsigned &n1, unsigned &n2, unsigned &n3) {
+    unsigned t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "v_and_b32_e32 %[t], 0xffff, %[d]\n\t"
+        "v_cmpx_le_u32_e32 %[p1], %[t]\n\t"
+        "v_add_u32_e32 %[n1], 1, %[n1]\n\t"
+        "v_cmpx_le_u32_e32 %[p2], %[t]\n\t"
+        "v_add_u32_e32 %[n2], 1, %[n2]\n\t"
+        "v_cmpx_le_u32_e32 %[p3], %[t]\n\t"
+        "v_add_u32_e32 %[n3], 1, %[n3]\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmpx_le_u32_e32 %[P1], %[d]\n\t"
+        "v_add_u32_e32 %[n1], 1, %[n1]\n\t"
+        "v_cmpx_le_u32_e32 %[P2], %[d]\n\t"
+        "v_add_u32_e32 %[n2], 1, %[n2]\n\t"
+        "v_cmpx_le_u32_e32 %[P3], %[d]\n\t"
+        "v_add_u32_e32 %[n3], 1, %[n3]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [n1] "+v"(n1), [n2] "+v"(n2), [n3] "+v"(n3), [t] "=&v"(t), [sv] "=&s"(sv)
+        : [d] "v"(d), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [P1] "s"(P1), [P2] "s"(P2), [P3] "s"(P3)
+        : "vcc");
+}
+
+// SAMP_STOP (diagnostic builds only, `make ablate A=s<n> S=<n>`): the kernel ends after phase n -- 1 row load + max, 2 masses + Z,
+// 3 top-p cutoff, 4 kept mass -- so that tools/sampler_bench.py under CHIRRUP_AMD_LIB gives the time up to there.
+#ifndef SAMP_STOP
+#define SAMP_STOP 0
+#endif
+#define SAMP_PHASE_END(n, v) if (SAMP_STOP == (n)) { if (tid == 0) ids[r] = (int32_t)(v); return; }
+// SAMP_STOP 9: workgroup b reports the time of interval (b % 8) in 10 ns ticks instead of the token: 0 load + max, 1 masses + Z,
+// 2 the compares of the eight cutoff passes, 3 their reductions, 4 top-k, 5 kept mass, 6 scan + draw, 7 everything
+#define SAMP_STAMP(i) if (SAMP_STOP == 9) st[i] = wall_clock64();
+
 __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
     const int V, const f16 *__restrict__ logits, const int32_t *__restrict__ rows, const f16 *__restrict__ temperature,
     const f16 *__restrict__ top_p, const int32_t *__restrict__ top_k, const int32_t *__restrict__ slot_idx,
@@ -204,89 +269,140 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
     const float P = (float)top_p[slot];
     const int Kk = top_k[slot];
     const f16 *src = logits + (int64_t)r * V;
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_cmp = 0, t_red = 0;
+    SAMP_STAMP(0)
 
-    // ---- row -> LDS, max
+    // ---- row -> LDS (for the token-order draw at the end) AND into registers: this lane's 64 tokens, eight groups of eight,
+    //      group g = tid + 1024 it; max
+    constexpr int kGroups = 65536 / kSampThreads / 8;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned kq[4 * kGroups];                                 // raw binary16 pairs first, order-preserving 16-bit keys after the max
     float mx = -INFINITY;
-    for (int c = tid * 8; c < V; c += kSampThreads * 8) {
-        const f16x8 v = *reinterpret_cast<const f16x8 *>(src + c);
-        *reinterpret_cast<f16x8 *>(row + c) = v;
 #pragma unroll
-        for (int e = 0; e < 8; e++) mx = fmaxf(mx, (float)v[e]);
+    for (int it = 0; it < kGroups; it++) {
+        const int c = 8 * (tid + it * kSampThreads);
+        if (c < V) {
+            const f16x8 v = *reinterpret_cast<const f16x8 *>(src + c);
+            *reinterpret_cast<f16x8 *>(row + c) = v;
+#pragma unroll
+            for (int e = 0; e < 8; e++) mx = fmaxf(mx, (float)v[e]);
+            const u32x4 q = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+            for (int e = 0; e < 4; e++) kq[4 * it + e] = q[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) kq[4 * it + e] = 0xfc00fc00u;          // -inf: mass 0, the smallest key
+        }
     }
     mx = block_reduce_max(mx, red);
-    // this lane's elements -- the token pairs {2 (tid + 1024 i), +1} -- as un-normalised mass in registers; their 16-bit
-    // order-preserving keys are re-derived from the row in LDS in every pass (two per 4-byte read; 64 masses AND 64 keys do not fit
-    // the 128 registers a lane of a 1024-lane workgroup has)
-    constexpr int kPairs = 65536 / kSampThreads / 2;
-    typedef f16 f16x2_t __attribute__((ext_vector_type(2)));
-    float ms[2 * kPairs];
+    const unsigned Kmax = key_of((f16)mx);             // the row's largest key (mx is one of its binary16 values)
+    SAMP_PHASE_END(1, Kmax)
+    SAMP_STAMP(1)
+    float ms[8 * kGroups];                             // un-normalised mass per token
     float z = 0.f;
 #pragma unroll
-    for (int i = 0; i < kPairs; i++) {
-        const int c = 2 * (tid + i * kSampThreads);
-        float m0 = 0.f, m1 = 0.f;
-        if (c < V) {                                 // (V is even: checked by the entry point)
-            const f16x2_t v = *reinterpret_cast<const f16x2_t *>(row + c);
-            m0 = __expf((float)v[0] - mx), m1 = __expf((float)v[1] - mx);
+    for (int it = 0; it < kGroups; it++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const unsigned d = kq[4 * it + e];
+            const f16 lo = __builtin_bit_cast(f16, (unsigned short)(d & 0xffffu)), hi = __builtin_bit_cast(f16, (unsigned short)(d >> 16));
+            const float m0 = __expf((float)lo - mx), m1 = __expf((float)hi - mx);
+            ms[8 * it + 2 * e] = m0, ms[8 * it + 2 * e + 1] = m1;
+            z += m0 + m1;
+            kq[4 * it + e] = 8 * (tid + it * kSampThreads) < V ? key_of(lo) | (key_of(hi) << 16) : 0u;   // past the row: key 0, below every threshold
         }
-        ms[2 * i] = m0, ms[2 * i + 1] = m1;
-        z += m0 + m1;
     }
     const float Z0 = block_reduce_sum(z, red);
     const float target = P * Z0;                 // in un-normalised mass
+    SAMP_PHASE_END(2, target)
+    SAMP_STAMP(2)
 
-    // ---- the cutoffs, by bisection over the key bits: c_key = the largest key with mass{key >= c_key} >= target, k_key = the
-    //      largest key with count{key >= k_key} >= K (top-k).  16 passes, one block reduction each.  (Rounds 1-2 built two-level
-    //      histograms in LDS with atomics: with real logits most tokens fall into a few bins, the same-address atomics serialise,
-    //      and the kernel took 167 us for 200 rows.)
+    // ---- the cutoffs, two key bits per pass: c_key = the largest OCCURRING key with mass{key >= c_key} >= target, k_key = the
+    //      largest key with count{key >= k_key} >= K (top-k).  Eight passes over registers only, one block reduction each.
+    //      (Rounds 1-2 built two-level histograms in LDS with atomics: with real logits most tokens fall into a few bins, the
+    //      same-address atomics serialise -- 167 us for 200 rows; one bit per pass with keys re-derived from LDS: 125-142 us.)
     unsigned c_key = 0, k_key = 0;
-    const bool use_k = Kk > 0;
-    unsigned *redu = hcnt;                       // [16]
-    for (int bit = 15; bit >= 0; bit--) {
-        const unsigned cp = c_key | (1u << bit), ck = k_key | (1u << bit);
-        float m = 0.f;
-        unsigned n = 0;                              // low half: tokens with key >= ck (top-k); high half: ... with key >= cp
+    float *redm = hmass;                         // [3][16]
+    unsigned *redn = hcnt;                       // [3][16]
+    for (int bit = 14; bit >= 0; bit -= 2) {
+        const unsigned p1 = c_key | (1u << bit), p2 = c_key | (2u << bit), p3 = c_key | (3u << bit);
+        float m1 = 0.f, m2 = 0.f, m3 = 0.f;
+        SAMP_STAMP(6)
 #pragma unroll
-        for (int i = 0; i < kPairs; i++) {
-            const int c = 2 * (tid + i * kSampThreads);
-            if (c < V) {
-                const f16x2_t v = *reinterpret_cast<const f16x2_t *>(row + c);
-                const unsigned k0 = key_of(v[0]), k1 = key_of(v[1]);
-                m += (k0 >= cp ? ms[2 * i] : 0.f) + (k1 >= cp ? ms[2 * i + 1] : 0.f);
-                n += (k0 >= cp ? 0x10000u : 0u) + (k1 >= cp ? 0x10000u : 0u);
-                if (use_k) n += (k0 >= ck ? 1u : 0u) + (k1 >= ck ? 1u : 0u);
+        for (int it = 0; it < kGroups; it++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                mass_ge3(kq[4 * it + e], ms[8 * it + 2 * e], ms[8 * it + 2 * e + 1], p1, p2, p3, p1 << 16, p2 << 16, p3 << 16, m1, m2, m3);
+        }
+        SAMP_STAMP(7)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+            m1 += __shfl_xor(m1, o, 64), m2 += __shfl_xor(m2, o, 64), m3 += __shfl_xor(m3, o, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) redm[tid >> 6] = m1, redm[16 + (tid >> 6)] = m2, redm[32 + (tid >> 6)] = m3;
+        __syncthreads();
+        float M1 = 0.f, M2 = 0.f, M3 = 0.f;
+        for (int w = 0; w < kSampThreads / 64; w++) M1 += redm[w], M2 += redm[16 + w], M3 += redm[32 + w];
+        // mass{key >= t} falls as t grows: the largest candidate that still holds the target, among keys that occur (t <= Kmax;
+        // top_p = 0 then ends at the row's largest key, i.e. greedy)
+        if (M3 >= target && p3 <= Kmax) c_key = p3;
+        else if (M2 >= target && p2 <= Kmax) c_key = p2;
+        else if (M1 >= target && p1 <= Kmax) c_key = p1;
+        if (SAMP_STOP == 9) t_cmp += st[7] - st[6], t_red += wall_clock64() - st[7];
+    }
+    SAMP_PHASE_END(3, c_key)
+    SAMP_STAMP(3)
+    if (Kk > 0) {                                // top-k: the same search over counts
+        for (int bit = 14; bit >= 0; bit -= 2) {
+            const unsigned q1 = k_key | (1u << bit), q2 = k_key | (2u << bit), q3 = k_key | (3u << bit);
+            unsigned n1 = 0, n2 = 0, n3 = 0;
+#pragma unroll
+            for (int it = 0; it < kGroups; it++) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) count_ge3(kq[4 * it + e], q1, q2, q3, q1 << 16, q2 << 16, q3 << 16, n1, n2, n3);
             }
-        }
-        const unsigned any_p = __any((n >> 16) != 0);        // (a count of 65536 would overflow the half: only "any" is asked of it)
-        n &= 0xffffu;                                          // per lane at most 64
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            m += __shfl_xor(m, o, 64);
-            n += __shfl_xor(n, o, 64);
+            for (int o = 32; o >= 1; o >>= 1)
+                n1 += __shfl_xor(n1, o, 64), n2 += __shfl_xor(n2, o, 64), n3 += __shfl_xor(n3, o, 64);
+            __syncthreads();
+            if ((tid & 63) == 0) redn[tid >> 6] = n1, redn[16 + (tid >> 6)] = n2, redn[32 + (tid >> 6)] = n3;
+            __syncthreads();
+            unsigned N1 = 0, N2 = 0, N3 = 0;
+            for (int w = 0; w < kSampThreads / 64; w++) N1 += redn[w], N2 += redn[16 + w], N3 += redn[32 + w];
+            if (N3 >= (unsigned)Kk) k_key = q3;
+            else if (N2 >= (unsigned)Kk) k_key = q2;
+            else if (N1 >= (unsigned)Kk) k_key = q1;
         }
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = m, redu[tid >> 6] = n | (any_p ? 0x80000000u : 0u);
-        __syncthreads();
-        float M = 0.f;
-        unsigned Nn = 0, anyp = 0;
-        for (int w = 0; w < kSampThreads / 64; w++) M += red[w], Nn += redu[w] & 0x7fffffffu, anyp |= redu[w] >> 31;
-        if (M >= target && anyp) c_key = cp;         // ... among the keys that occur (top_p = 0: the row's largest key, i.e. greedy)
-        if (use_k && Nn >= (unsigned)Kk) k_key = ck;
     }
     const unsigned thr = (Kk > 0 && k_key > c_key) ? k_key : c_key;
+    SAMP_STAMP(4)
 
     // ---- kept mass after temperature, then inverse-CDF draw in token order
+    // p^(1/T) with p = exp(v - mx) / Z0 is exp((v - mx - ln Z0) / T): one exponential per kept token (powf here cost 80 us per
+    // launch at top_p 0.9)
     const float invT = 1.0f / T;
     const bool hot = T != 1.0f;
+    const float lnZ = __logf(Z0);
+    auto weight = [&](float v) -> float { return hot ? __expf((v - mx - lnZ) * invT) : __expf(v - mx) / Z0; };
     const int per = (V + kSampThreads - 1) / kSampThreads;       // contiguous chunk per thread
     const int c0 = tid * per, c1 = (c0 + per) < V ? (c0 + per) : V;
     float local = 0.f;
-    for (int c = c0; c < c1; c++) {
-        if (key_of(row[c]) >= thr) {
-            float p = __expf((float)row[c] - mx) / Z0;
-            local += hot ? powf(p, invT) : p;
+    if ((per & 7) == 0 && c0 + per <= V) {             // the usual vocabulary: 16-byte LDS reads (64 two-byte reads at a 128-byte lane
+                                                       // stride are 32-way bank conflicts each)
+        for (int c = c0; c < c1; c += 8) {
+            const f16x8 v8 = *reinterpret_cast<const f16x8 *>(row + c);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (key_of(v8[e]) >= thr) local += weight((float)v8[e]);
+            }
+        }
+    } else {
+        for (int c = c0; c < c1; c++) {
+            if (key_of(row[c]) >= thr) local += weight((float)row[c]);
         }
     }
+    SAMP_PHASE_END(4, __shfl_xor(local, 1, 64))
+    SAMP_STAMP(5)
     // exclusive scan of `local` over the 1024 threads
     float incl = local;
 #pragma unroll
@@ -307,8 +423,7 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
         float acc = before; int pick = -1;
         for (int c = c0; c < c1; c++) {
             if (key_of(row[c]) >= thr) {
-                float p = __expf((float)row[c] - mx) / Z0;
-                acc += hot ? powf(p, invT) : p;
+                acc += weight((float)row[c]);
                 pick = c;
                 if (acc > want) break;
             }
@@ -322,6 +437,11 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
             for (int c = V - 1; c >= 0; c--) if (key_of(row[c]) >= thr) { pick = c; break; }
         }
         ids[r] = pick;
+        if (SAMP_STOP == 9) {
+            const unsigned long long t_end = wall_clock64();
+            const unsigned long long d[8] = {st[1] - st[0], st[2] - st[1], t_cmp, t_red, st[4] - st[3], st[5] - st[4], t_end - st[5], t_end - st[0]};
+            ids[r] = (int32_t)d[blockIdx.x & 7];
+        }
     }
 }
 
