@@ -150,16 +150,16 @@ extern "C" int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int3
 // softmax(logits); cutoff = the probability at which the DESCENDING cumulative sum first reaches top_p,
 // everything below it is dropped (ties at the cutoff stay); optional top-k; probs ** (1/T); one draw
 // from the remaining mass.  The reference sorts all V probabilities per row; here the row's binary16
-// logits sit in LDS (V <= 65536 -> 128 KiB) and the cutoff is found by a two-level radix search over
-// the 16-bit order-preserving keys of the logits (probability is monotone in the logit), 256 bins of
-// probability mass (and of counts, for top-k) per level.  The draw is an inverse-CDF walk in token
+// logits sit in LDS (V <= 65536 -> 128 KiB) and the cutoff is found by a search over the bits of the
+// 16-bit order-preserving keys of the logits (probability is monotone in the logit), two bits per pass
+// over masses and packed keys held in registers (counts, for top-k).  The draw is an inverse-CDF walk in token
 // order with a caller-supplied uniform number per row (torch's generator stays the source of
 // randomness).  Differences from the reference: ties AT the top-k boundary are all kept, and the
 // draw uses one uniform instead of torch.multinomial's stream -- same distribution, different ids.
 namespace {
 
 constexpr int kSampThreads = 1024;
-constexpr int kHistReplicas = 8;
+constexpr int kSampRed = 3 * 16;               // one slot per (threshold, wave) of a block reduction
 
 __device__ __forceinline__ unsigned key_of(f16 v) {        // larger value <=> larger key
     const unsigned short b = __builtin_bit_cast(unsigned short, v);
@@ -258,9 +258,9 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
     const float *__restrict__ uniform, int32_t *__restrict__ ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f16 *row = reinterpret_cast<f16 *>(smem);                                   // V halves (padded to 8)
-    float *hmass = reinterpret_cast<float *>(smem + ((size_t)V * 2 + 15) / 16 * 16);   // [replicas][256]
-    unsigned *hcnt = reinterpret_cast<unsigned *>(hmass + kHistReplicas * 256);  // [replicas][256]
-    float *red = reinterpret_cast<float *>(hcnt + kHistReplicas * 256);          // [16]
+    float *redm = reinterpret_cast<float *>(smem + ((size_t)V * 2 + 15) / 16 * 16);    // [3][16] masses of a pass, per wave
+    unsigned *redn = reinterpret_cast<unsigned *>(redm + kSampRed);              // [3][16] counts
+    float *red = reinterpret_cast<float *>(redn + kSampRed);                     // [16]
     float *scal = red + 16;                                                      // small broadcast area
     const int tid = threadIdx.x;
     const int r = rows[blockIdx.x];
@@ -322,8 +322,6 @@ __global__ __launch_bounds__(kSampThreads) void sample_topp_kernel(
     //      (Rounds 1-2 built two-level histograms in LDS with atomics: with real logits most tokens fall into a few bins, the
     //      same-address atomics serialise -- 167 us for 200 rows; one bit per pass with keys re-derived from LDS: 125-142 us.)
     unsigned c_key = 0, k_key = 0;
-    float *redm = hmass;                         // [3][16]
-    unsigned *redn = hcnt;                       // [3][16]
     for (int bit = 14; bit >= 0; bit -= 2) {
         const unsigned p1 = c_key | (1u << bit), p2 = c_key | (2u << bit), p3 = c_key | (3u << bit);
         float m1 = 0.f, m2 = 0.f, m3 = 0.f;
@@ -453,7 +451,7 @@ extern "C" int rwkv7_sample_topp(int n_rows, int V, const void *logits, const in
     if (n_rows <= 0 || V <= 0 || (V & 7) || V > 65536) return CHIRRUP_E_SHAPE;
     if (!logits || !rows || !temperature || !top_p || !top_k || !uniform || !ids) return CHIRRUP_E_NULL;
     if (reinterpret_cast<uintptr_t>(logits) & 15) return CHIRRUP_E_ALIGN;
-    const size_t lds = ((size_t)V * 2 + 15) / 16 * 16 + (size_t)kHistReplicas * 256 * 8 + 16 * 4 + 8 * 4;
+    const size_t lds = ((size_t)V * 2 + 15) / 16 * 16 + (size_t)kSampRed * 8 + 16 * 4 + 8 * 4;
     static std::atomic<bool> attr_set[32];    // per device: one engine process may drive several GPUs from several threads
     int dev = 0;                              // (the attribute call is idempotent; the flag only saves repeating it)
     (void)hipGetDevice(&dev);
