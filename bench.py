@@ -619,7 +619,8 @@ def main():
     engine_dt = None
     if not a.no_engine_leg and not a.no_graph and not a.no_fused:
         del state
-        engine_dt = engine_iterations(model, B, a, dev, rank, a.steps)
+        engine_steps = max(a.steps, 60)              # (20 iterations are 0.14 s: box-to-box clock drift showed up as 1.00-1.035x)
+        engine_dt = engine_iterations(model, B, a, dev, rank, engine_steps)
         state = make_state(model, B)
     gemm_t = gemm_shape_timings(model, B) if (rank == 0 and not os.environ.get("CHIRRUP_BENCH_NO_GEMM_LEG")) else {}      # (the env switch: per-kernel profiles of the step alone)
     clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
@@ -682,10 +683,10 @@ def main():
         out["tmix_launch_status"] = _ops2.chain_status()      # 0: no bounded in-launch wait of the time-mix launches ever gave up
         assert out["tmix_launch_status"] == 0, "a time-mix launch gave up waiting for its own workgroups: results undefined"
         if engine_dt is not None:
-            ems = engine_dt / a.steps * 1e3
+            ems = engine_dt / engine_steps * 1e3
             out["engine"] = {"what": "the same batch through chirrup_amd.worker.Worker.step() (slot pool, graph decode, fused sampler, "
                                      "host bookkeeping + messages, run-ahead), one worker process per GPU", "ms_per_iteration": round(ems, 4),
-                             "value": round(world * B * a.steps / engine_dt, 1), "unit": "tokens/s", "tps_per_request": round(1e3 / ems, 2),
+                             "value": round(world * B * engine_steps / engine_dt, 1), "iterations": engine_steps, "unit": "tokens/s", "tps_per_request": round(1e3 / ems, 2),
                              "vs_bare_step": round(ems / ms_per_step, 4)}
         if regions:
             out["ms_per_step_median"] = round(regions[len(regions) // 2], 4)
