@@ -46,6 +46,9 @@ constexpr uint32_t kRo1 = 2654435769u;
 #ifndef WKV7_MIN_WAVES
 #define WKV7_MIN_WAVES 1      // __launch_bounds__ second argument (waves per SIMD)
 #endif
+#ifndef WKV7_FUSED_WAVES
+#define WKV7_FUSED_WAVES 4    // the fused decode form: 4 waves per SIMD (128 registers) instead of the 132 the compiler takes by itself
+#endif
 #ifndef WKV7_ENTRY_SUFFIX
 #define WKV7_ENTRY_SUFFIX
 #endif
@@ -108,7 +111,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // a third of it, and no load latency is exposed (eight tokens of prefetch instead of one: slower, the code no longer
 // fits the instruction cache -- profiles/r02_prefill_B25_T100.txt).
 template <int MODE, bool DECAYED = false>
-__global__ __launch_bounds__(64, WKV7_MIN_WAVES) void wkv7_seq_kernel(
+__global__ __launch_bounds__(64, (MODE == 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WAVES : WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const int T, const int C, const int H, f16 *__restrict__ state, const int64_t slot_stride,
     const int32_t *__restrict__ slot_idx, const f16 *__restrict__ r_, const f16 *__restrict__ w_,
     const f16 *__restrict__ k_, const f16 *__restrict__ v_, const f16 *__restrict__ a_,
