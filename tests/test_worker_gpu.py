@@ -212,6 +212,64 @@ def test_sample_topp_distribution(V, temp, top_p, top_k):
         assert bool((draws == int(p.argmax())).all())
 
 
+@pytest.mark.parametrize("V", [1000, 50304, 65536])
+def test_sample_topp_kept_set_and_the_ends_of_the_walk(V):
+    """Per-row settings through slot tables, vocabularies that do not fill the kernel's 8192-token strides, and the two ends of
+    the inverse-CDF walk: with u = 0 the draw is the FIRST token (in id order) of the kept set the reference's algorithm defines
+    (chirrup/utils/samplers.py:171-255: cutoff by value at the first crossing of top_p, ties kept, then top-k), with u just
+    below 1 the LAST one; nothing outside the set is drawn for u in between."""
+    from chirrup_amd import ops
+
+    torch.manual_seed(V)
+    top_p = [0.1, 0.5, 0.9, 0.3, 0.7, 1.0]
+    top_k = [0, 0, 0, 3, 50, 0]
+    n = len(top_p)
+    logits = (torch.randn(n, V) * 2.5)
+    logits[:, :8] -= 30.0                 # the first and last tokens far outside every kept set but top_p = 1's
+    logits[:, -8:] -= 30.0
+    logits = logits.half().cuda()
+    prob = torch.softmax(logits.float(), -1).cpu()
+    kept = []                             # per row: the kept sets for the crossing index and its two neighbours (the kernel adds the
+    for i in range(n):                    # same masses in another order: a crossing within ~1e-5 of top_p may fall one token either way)
+        sp, _ = torch.sort(prob[i], descending=True)
+        cs = torch.cumsum(sp, 0)
+        tpv = float(torch.tensor(top_p[i]).half())
+        j = min(int(torch.searchsorted(cs, torch.tensor(tpv))), V - 1)
+        near = [j] + [jj for jj in (j - 1, j + 1) if 0 <= jj < V and min(abs(float(cs[max(jj, j) - 1]) - tpv), abs(float(cs[min(jj, j)]) - tpv)) < 1e-5]
+        sets = []
+        for jj in near:
+            keep = prob[i] >= sp[jj]
+            if top_k[i] > 0:
+                keep &= prob[i] >= sp[top_k[i] - 1]
+            sets.append(keep)
+        kept.append(sets)
+    # slots in a permuted order, rows listed out of order
+    slot_idx = torch.tensor([4, 2, 5, 0, 1, 3], dtype=torch.int32, device="cuda")
+    t = torch.ones(n, dtype=torch.float16, device="cuda")
+    tp = torch.zeros(n, dtype=torch.float16, device="cuda")
+    tk = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for i in range(n):
+        tp[int(slot_idx[i])] = top_p[i]
+        tk[int(slot_idx[i])] = top_k[i]
+    rows = torch.tensor([3, 0, 5, 1, 4, 2], dtype=torch.int32, device="cuda")
+
+    def draw(u):
+        ids = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        ops.sample_topp(logits, rows, t, tp, tk, torch.full((n,), u, dtype=torch.float32, device="cuda"), ids, slot_idx=slot_idx)
+        return ids.cpu().tolist()
+
+    first, last, mid = draw(0.0), draw(1.0 - 2.0 ** -24), draw(0.37)
+    for i in range(n):
+        if top_p[i] == 1.0:             # where binary32 cumsum first reaches 1.0 is rounding in the reference too (it drops < 1e-6 of mass
+            assert all(0 <= v < V for v in (first[i], mid[i], last[i]))      # there or nothing); the kernel keeps every token
+            continue
+        ok = False
+        for keep in kept[i]:
+            idx = torch.nonzero(keep).flatten()
+            ok |= first[i] == int(idx[0]) and bool(keep[mid[i]]) and last[i] == int(idx[-1])
+        assert ok, (i, first[i], mid[i], last[i], [int(torch.nonzero(k).flatten()[0]) for k in kept[i]], [int(k.sum()) for k in kept[i]])
+
+
 @pytest.mark.parametrize("worker_has_arena", [False, True], ids=["clone_export", "arena_export"])
 def test_prefix_cache_in_hbm_arena_round_trip(worker_has_arena):
     """Row 8f-1 end to end: the worker exports a prefix state (device-resident; with an arena straight into a free row:
