@@ -47,7 +47,7 @@ constexpr uint32_t kRo1 = 2654435769u;
 #define WKV7_MIN_WAVES 1      // __launch_bounds__ second argument (waves per SIMD)
 #endif
 #ifndef WKV7_FUSED_WAVES
-#define WKV7_FUSED_WAVES 4    // the fused decode form: 4 waves per SIMD (128 registers) instead of the 132 the compiler takes by itself
+#define WKV7_FUSED_WAVES 4    // the fused decode forms: 4 waves per SIMD (the 8.8-KB strip per wave allows 4.5); MODE 2 takes 132 registers by itself
 #endif
 #ifndef WKV7_ENTRY_SUFFIX
 #define WKV7_ENTRY_SUFFIX
@@ -101,7 +101,7 @@ struct TmixArgs {
 typedef __attribute__((address_space(1))) const void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-// MODE 0: the operator of the reference (inputs a = -kk, b = kk*a given).  MODE 1: fused time-mix core:
+// MODE 0: the operator of the reference (inputs a = -kk, b = kk*a given).  MODE 1 (MODE 2: + the mm8 prologue of TmixArgs): fused time-mix core:
 // k, v are the RAW projections, a_/b_ are unused, y_ receives (group_norm(y) + bonus*v) * g.
 // DECAYED (MODE 0 only): w_ already holds w~ (wkv7_decay_kernel below) -- for chunks of many tokens everything that does
 // not depend on the state is computed by row-parallel kernels (rwkv7_tmix_mid, wkv7_decay, rwkv7_tmix_post) and the
@@ -111,7 +111,7 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // a third of it, and no load latency is exposed (eight tokens of prefetch instead of one: slower, the code no longer
 // fits the instruction cache -- profiles/r02_prefill_B25_T100.txt).
 template <int MODE, bool DECAYED = false>
-__global__ __launch_bounds__(64, (MODE == 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WAVES : WKV7_MIN_WAVES) void wkv7_seq_kernel(
+__global__ __launch_bounds__(64, (MODE >= 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WAVES : WKV7_MIN_WAVES) void wkv7_seq_kernel(
     const int T, const int C, const int H, f16 *__restrict__ state, const int64_t slot_stride,
     const int32_t *__restrict__ slot_idx, const f16 *__restrict__ r_, const f16 *__restrict__ w_,
     const f16 *__restrict__ k_, const f16 *__restrict__ v_, const f16 *__restrict__ a_,
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64, (MODE == 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WA
         gj = tm.g[o];
         if (tm.v_first) { vgj = tm.vg_pre[o]; vfj = tm.v_first[o]; }
         p_kk = tm.k_k[ch]; p_ka = tm.k_a[ch]; p_rk = tm.r_k[ch]; p_lw = tm.lnx_w[ch]; p_lb = tm.lnx_b[ch];
-        if (tm.q_ry) { p_ry = tm.q_ry[ch]; p_my = tm.q_my[ch]; }
+        if (MODE == 2) { p_ry = tm.q_ry[ch]; p_my = tm.q_my[ch]; }
     }
     const int32_t et = elapsed_t[bb];
 
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64, (MODE == 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WA
         const float dither = kTwoToNeg41 * (float)(int32_t)(kRo1 * (uint32_t)(et + t));
         f16 k_in = kj, a_in = aj, b_in = bj, vv = vi;
         const f16 r_cur = rj, g_cur = gj;
-        if (MODE == 1) {
+        if (MODE >= 1) {
             // rwkv7.py:629-637, one rounding per torch op; the head's L2 norm is a wavefront reduction
             const float a = (float)hf(sigmoid_f((float)aj));
             const float kk_in = (float)hf((float)kj * (float)p_kk);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64, (MODE == 1 && WKV7_FUSED_WAVES) ? WKV7_FUSED_WA
             const float gn = (float)hf(dlt * rstd * (float)p_lw + (float)p_lb);
             const float bonus = (float)hf(wave_sum((float)hf((float)hf((float)r_cur * (float)k_in) * (float)p_rk)));
             const f16 out = hf((float)hf(gn + (float)hf(bonus * (float)vv)) * (float)g_cur);
-            if (tm.q_ry) {                                  // mm8 prologue of att.output (mm8_prep_kernel's arithmetic)
+            if (MODE == 2) {                                // mm8 prologue of att.output (mm8_prep_kernel's arithmetic)
                 const f16 xs = hf((float)out * (float)p_ry);
                 const float s0 = wave_sum((float)xs), s1 = wave_sum((float)out * (float)p_my), s2 = wave_sum((float)out);
                 y_[o_cur] = xs;
@@ -447,10 +447,17 @@ extern "C" int rwkv7_tmix_wkv7_fused_mm8(int B, int T, int C, int H, void *state
                 static_cast<const f16 *>(g), static_cast<const f16 *>(k_k), static_cast<const f16 *>(k_a),
                 static_cast<const f16 *>(r_k), static_cast<const f16 *>(lnx_w), static_cast<const f16 *>(lnx_b), eps,
                 static_cast<const f16 *>(ry), static_cast<const f16 *>(my), S};
-    hipLaunchKernelGGL(wkv7_seq_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
-                       static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
-                       static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v), nullptr, nullptr,
-                       static_cast<f16 *>(out), elapsed_t, tm);
+    // (the prologue is a template form of its own: as a run-time branch it cost the binary16 form 4 registers past 128, i.e. a wave per SIMD)
+    if (ry)
+        hipLaunchKernelGGL(wkv7_seq_kernel<2>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
+                           static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
+                           static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v), nullptr, nullptr,
+                           static_cast<f16 *>(out), elapsed_t, tm);
+    else
+        hipLaunchKernelGGL(wkv7_seq_kernel<1>, dim3((unsigned)(B * H)), dim3(64), 0, static_cast<hipStream_t>(stream), T, C, H,
+                           static_cast<f16 *>(state), slot_stride, slot_idx, static_cast<const f16 *>(r),
+                           static_cast<const f16 *>(w), static_cast<const f16 *>(k), static_cast<const f16 *>(v), nullptr, nullptr,
+                           static_cast<f16 *>(out), elapsed_t, tm);
     return (int)hipGetLastError();
 }
 #endif
