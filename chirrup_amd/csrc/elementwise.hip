@@ -197,14 +197,16 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
 // One workgroup per R consecutive (b, t) rows of a sequence.
 // PROBE: the diagnostic instantiation that writes phase stamps (the stamp code costs the 1024-lane forms 4-12 registers and a
 // spill: 11.7 -> 13.4 us for LN1 at 7.2B / bsz 200 while it sat in the product kernel behind a run-time null check).
-template <int NMIX, int TH, bool PROBE = false>
+// Q: the mm8 (w8a16) hooks of chirrup_mm8_fuse are live; the binary16 model's launches instantiate the kernel without them.
+template <int NMIX, int TH, bool PROBE = false, bool Q = true>
 __global__ __launch_bounds__(TH) void add_ln_mix_kernel(
     const int T, const int C, const f16 *x, const f16 *__restrict__ delta, f16 *x_out,
     const f16 *__restrict__ ln_w, const f16 *__restrict__ ln_b, const float eps, const f16 *__restrict__ prev_in,
     f16 *__restrict__ prev_out, const f16 *__restrict__ mix, f16 *__restrict__ out, const int64_t out_stride,
     const int32_t *__restrict__ slot_idx, const float *__restrict__ dpart, const int dsplits, const int64_t dsplit_stride,
-    const chirrup_mm8_fuse fz, const int R, unsigned long long *stamps_) {
+    const chirrup_mm8_fuse fz_, const int R, unsigned long long *stamps_) {
     unsigned long long *const stamps = PROBE ? stamps_ : nullptr;
+    const chirrup_mm8_fuse fz = Q ? fz_ : chirrup_mm8_fuse{};
     // diagnostic (rwkv7_ln_probe; tools/ln_timeline.py): 100-MHz stamps of a workgroup's phases, 8 per workgroup
     auto stamp = [&](int i) {
         if (stamps && threadIdx.x == 0) stamps[(int64_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
@@ -525,6 +527,8 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
     do {                                                                                           \
         if (g_ln_probe && TH == 1024) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024, true>), grid, block, 0, st, ARGS);  \
         else if (g_ln_probe && TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256, true>), grid, block, 0, st, ARGS);  \
+        else if (!fuse && TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256, false, false>), grid, block, 0, st, ARGS);  \
+        else if (!fuse && TH == 1024) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024, false, false>), grid, block, 0, st, ARGS);  \
         else if (TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256>), grid, block, 0, st, ARGS);  \
         else if (TH == 512) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 512>), grid, block, 0, st, ARGS); \
         else hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024>), grid, block, 0, st, ARGS);           \
