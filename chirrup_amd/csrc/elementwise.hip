@@ -529,6 +529,7 @@ extern "C" int rwkv7_add_ln_mix_mm8(int B, int T, int C, int n_mix, const void *
         else if (g_ln_probe && TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256, true>), grid, block, 0, st, ARGS);  \
         else if (!fuse && TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256, false, false>), grid, block, 0, st, ARGS);  \
         else if (!fuse && TH == 1024) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024, false, false>), grid, block, 0, st, ARGS);  \
+        else if (!fuse && TH == 512) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 512, false, false>), grid, block, 0, st, ARGS);  \
         else if (TH == 256) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 256>), grid, block, 0, st, ARGS);  \
         else if (TH == 512) hipLaunchKernelGGL((add_ln_mix_kernel<NM, 512>), grid, block, 0, st, ARGS); \
         else hipLaunchKernelGGL((add_ln_mix_kernel<NM, 1024>), grid, block, 0, st, ARGS);           \
