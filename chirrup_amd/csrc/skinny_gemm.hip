@@ -297,6 +297,9 @@ __device__ __forceinline__ void read_w_frags(const unsigned char *wt, const int 
 #ifndef RING_INTERLEAVE
 #define RING_INTERLEAVE 1
 #endif
+#ifndef RING_DIRECT_PARTIAL
+#define RING_DIRECT_PARTIAL 0
+#endif
 template <int MT, typename Mid>
 __device__ __forceinline__ void mma_kblock(const unsigned char *xt, const f16x8 (&wf)[2][2], const int c, const int q, f32x4 (&acc)[2][MT],
                                            Mid &&mid) {
@@ -742,6 +745,29 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
         if (bs.timeline) bs.timeline[4 * wg] = t_entry, bs.timeline[4 * wg + 1] = rt0, bs.timeline[4 * wg + 2] = __builtin_amdgcn_s_memrealtime();
     }
     float *stg = reinterpret_cast<float *>(smem);      // the ring is no longer needed (MT*16 rows x 528 B <= its size)
+#if RING_DIRECT_PARTIAL
+    // A/B build (make ablate A=dp X=-DRING_DIRECT_PARTIAL=1): binary32 partial planes straight from the accumulators -- a lane holds 4
+    // consecutive columns of a row, 4 lanes cover 64 B of it -- without the round trip through LDS and its two barriers
+    if constexpr (EPI == EPI_PARTIAL && !W8) {
+        if (wave_live) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const int m = mt * 16 + c;
+                if (m >= t.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    const int n = n0 + 16 * nt + 4 * q;
+                    if (n < t.Np) *reinterpret_cast<f32x4 *>(t.part + ((int64_t)t.kslice * M + m) * t.Np + n) = acc[nt][mt];
+                }
+            }
+        }
+        if (bs.timeline && tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bs.timeline[4 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+        return;
+    }
+#endif
     __syncthreads();                                   // every compute wave is past its last fragment read
     if (wave_live) stage_acc<MT>(stg, acc, t.M, wave * 32, c, q);
     __syncthreads();
