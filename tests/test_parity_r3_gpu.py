@@ -265,3 +265,47 @@ def test_ln_kernel_lanes_past_the_row_touch_nothing(C, B, T, n_mix, splits):
         assert bool((views["x_out"] == 7.0).all()) and bool((views["prev_out"] == 7.0).all())            # not given: not written
         d = np.abs(out[0].cpu().numpy().astype(F32) - cur.astype(F32))
         assert d.max() <= 8e-3, float(d.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C", [768, 2048, 4096])
+@pytest.mark.parametrize("n_mix", [0, 1, 6])
+def test_ln_kernel_without_mm8_hooks_is_the_same_kernel(C, n_mix):
+    """Launches without a chirrup_mm8_fuse record run an instantiation of add_ln_mix_kernel that was compiled without the mm8
+    hooks ("Bugs found in round 3": as run-time branches they cost the binary16 model registers).  With an all-null
+    record the other instantiation runs: the two must write the same bits (decode form with folded split-K partials, and a
+    four-token chunk)."""
+    import ctypes
+
+    from chirrup_amd import ops
+
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(C + n_mix)
+    for B, T, splits in ((5, 1, 8), (2, 4, 0)):
+        x = torch.randn(B, T, C, generator=g).half().to(dev)
+        part = (torch.randn(splits, B * T, C, generator=g) * 0.3).to(dev) if splits else None
+        delta = None if splits else (torch.randn(B, T, C, generator=g) * 0.3).half().to(dev)
+        ln_w, ln_b = (1 + 0.1 * torch.randn(C, generator=g)).half().to(dev), (0.1 * torch.randn(C, generator=g)).half().to(dev)
+        prev = torch.randn(B, C, generator=g).half().to(dev)
+        mix = torch.rand(n_mix, C, generator=g).half().to(dev) if n_mix else None
+        outs = []
+        for with_record in (False, True):
+            x_out, prev_out = torch.empty_like(x), torch.empty_like(prev)
+            out = torch.full((max(n_mix, 1), B, T, C), float("nan"), dtype=torch.float16, device=dev)
+            if not with_record:
+                ops.add_ln_mix(B, T, C, x, delta, x_out, ln_w, ln_b, 1e-5, prev if n_mix else None, prev_out if n_mix else None, mix, out,
+                               delta_partials=part)
+            else:
+                fz = ops._Mm8Fuse()                    # every hook null: the instantiation with the hooks compiled in
+                rc = ops._lib.load().rwkv7_add_ln_mix_mm8(
+                    B, T, C, n_mix, ops._ptr(x), ops._ptr(delta), ops._ptr(x_out), ops._ptr(ln_w), ops._ptr(ln_b), 1e-5,
+                    ops._ptr(prev if n_mix else None), ops._ptr(prev_out if n_mix else None), ops._ptr(mix), ops._ptr(out), B * T * C, None,
+                    ops._ptr(part), splits, ctypes.addressof(fz), ops._stream())
+                assert rc == 0
+            torch.cuda.synchronize()
+            outs.append((out.clone(), x_out.clone(), prev_out.clone() if n_mix else None))
+        same = lambda u, v: torch.equal(u.view(torch.int16), v.view(torch.int16))
+        assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1])
+        if n_mix:
+            assert same(outs[0][2], outs[1][2])
+        assert not torch.isnan(outs[0][0].float()).any()
