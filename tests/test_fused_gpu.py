@@ -173,6 +173,45 @@ def test_fused_tmix_core_equals_three_kernel_path(oracle, B, T, C, layer0):
     assert_close_ulps(out1.cpu().numpy(), out3.cpu().numpy(), 2, 0.05, "out", atol=4e-3 * max(1.0, float(out3.abs().max())))
 
 
+@pytest.mark.parametrize("B,T,C,layer0", [(3, 1, 128, True), (4, 3, 256, False), (64, 1, 4096, False)])
+def test_fused_tmix_core_with_the_mm8_prologue_is_the_same_kernel(B, T, C, layer0):
+    """The mm8 prologue of the fused time-mix core is a template form of its own (as a run-time branch it cost the binary16 form
+    a wave per SIMD).  With ry = 1 the prologue's xs = binary16(o * ry) IS o: both forms must write the same output
+    and state bits, and the prologue's third row sum must be the sum of o over the head."""
+    from chirrup_amd import ops
+    from util import wkv7_inputs
+
+    rng = np.random.default_rng(B + T + C + 7)
+    H = C // 64
+    state, r, w, k, v, _, _, et = wkv7_inputs(B, T, C, seed=B * 5 + C)
+    mk = lambda s=1.0: (rng.standard_normal((B, T, C)) * s).astype(F16)
+    a_pre, vg_pre, v_first, g = mk(), mk(), mk(), mk()
+    k_k = (0.85 + 0.05 * rng.standard_normal(C)).astype(F16)
+    k_a = (1 + 0.05 * rng.standard_normal(C)).astype(F16)
+    r_k = (0.1 * rng.standard_normal(C)).astype(F16)
+    lw = (1 + 0.1 * rng.standard_normal(C)).astype(F16)
+    lb = (0.1 * rng.standard_normal(C)).astype(F16)
+    res = []
+    for prologue in (False, True):
+        S = cu(state)
+        out = torch.empty((B, T, C), dtype=torch.float16, device="cuda")
+        mm8_out = None
+        if prologue:
+            sums = torch.full((B * T, H, 3), float("nan"), dtype=torch.float32, device="cuda")
+            mm8_out = (torch.ones(C, dtype=torch.float16, device="cuda"), torch.zeros(C, dtype=torch.float16, device="cuda"), sums)
+        ops.tmix_wkv7_fused(B, T, C, H, S, cu(r), cu(w), cu(k), cu(v), cu(a_pre), None if layer0 else cu(vg_pre),
+                            None if layer0 else cu(v_first), cu(g), cu(k_k), cu(k_a), cu(r_k), cu(lw), cu(lb), 64e-5, out, cu(et),
+                            mm8_out=mm8_out)
+        torch.cuda.synchronize()
+        res.append((out, S, mm8_out[2] if prologue else None))
+    assert torch.equal(res[0][0].view(torch.int16), res[1][0].view(torch.int16))
+    assert torch.equal(res[0][1].view(torch.int16), res[1][1].view(torch.int16))
+    sums = res[1][2]
+    want = res[0][0].float().view(B * T, H, 64).sum(-1)
+    assert torch.allclose(sums[..., 0], want, rtol=1e-5, atol=1e-3) and torch.allclose(sums[..., 2], want, rtol=1e-5, atol=1e-3)
+    assert float(sums[..., 1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("rows,C", [(5, 128), (200, 1024)])
 def test_mm8_chain_folded_into_neighbouring_kernels_equals_mm8t_linear(rows, C):
     """Decode-regime mm8 FFN: the activation prologue of ffn.key written by the LN kernel, corrections + relu^2 of ffn.key
