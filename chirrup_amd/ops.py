@@ -106,6 +106,33 @@ _pair_counters = {}
 PAIR_REDUCE = True         # False: 2-way splits always go through the reduce launch (A/B; the results are the same bits)
 
 
+_sync_backing = {}
+
+
+def _sync_arena(device):
+    """(tile counters, time-mix hand-off words) of the current stream: two views of ONE zero-initialised int32 tensor per device
+    and stream, so that a decode graph zeroes both with one fill node (reset_launch_sync).  Returns (backing, created)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    b = _sync_backing.get(key)
+    if b is not None:
+        return b, False
+    L = _lib.load()
+    n_pair = (L.skinny_gemm_pair_counters() + 63) // 64 * 64
+    b = _sync_backing[key] = torch.zeros(n_pair + L.rwkv7_tmix_sync_words() + 2, dtype=torch.int32, device=device)
+    _pair_counters[key] = b[:L.skinny_gemm_pair_counters()]
+    _chain_sync[key] = b[n_pair:]
+    return b, True
+
+
+def reset_launch_sync(device=None) -> None:
+    """Zero the tile counters AND the time-mix hand-off words of the current stream with one fill (a single node at the head of
+    a captured decode graph; round 3's graphs carried four: each buffer's allocation-time fill was captured besides its reset)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    b, created = _sync_arena(dev)
+    if not created:
+        b.zero_()
+
+
 def _tile_counters(device):
     """Zeroed tile counters for the in-launch reduction of 2..4-way splits at <= 32 rows (include/chirrup_amd.h: tile_counters), one
     set per device and stream like the workspace: launches on one stream run in order, which is all the kernels need."""
@@ -114,8 +141,8 @@ def _tile_counters(device):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     t = _pair_counters.get(key)
     if t is None:
-        t = torch.zeros(_lib.load().skinny_gemm_pair_counters(), dtype=torch.int32, device=device)
-        _pair_counters[key] = t
+        _sync_arena(device)
+        t = _pair_counters[key]
     return t
 
 
@@ -642,7 +669,8 @@ def _chain_state(device, nbytes: int):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     sync = _chain_sync.get(key)
     if sync is None:
-        sync = _chain_sync[key] = torch.zeros(_lib.load().rwkv7_tmix_sync_words() + 2, dtype=torch.int32, device=device)
+        _sync_arena(device)
+        sync = _chain_sync[key]
     ws = _chain_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         # 32 MiB up front: more than any decode shape needs (slabs <= 4 MiB, split R/K/V partials <= 13 MiB), so that the buffer a

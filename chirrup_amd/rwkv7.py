@@ -885,8 +885,7 @@ class DecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            ops.reset_tile_counters(model.device)         # a memset node: every replay starts from zeroed tile counters
-            ops.reset_chain_sync(model.device)            # ... and zeroed hand-off words of the time-mix launches
+            ops.reset_launch_sync(model.device)           # one fill node: every replay starts from zeroed tile counters and hand-off words
             self.logits = model.forward_seq_batch(self.tokens, state)
         torch.cuda.synchronize()
         for t, s in zip(state, snap):
@@ -932,8 +931,7 @@ class SlotDecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            ops.reset_tile_counters(dev)                  # a memset node: every replay starts from zeroed tile counters
-            ops.reset_chain_sync(dev)
+            ops.reset_launch_sync(dev)                    # one fill node: every replay starts from zeroed tile counters and hand-off words
             self.logits = fwd()
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):
