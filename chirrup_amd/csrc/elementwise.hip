@@ -594,3 +594,57 @@ extern "C" int rwkv7_lora_act(int nplanes, int first_plane, int64_t plane_elems,
                        static_cast<hipStream_t>(stream), chunks, first_plane, (f16 *)hbuf, nplanes);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// The two ends of a decode step that were torch kernels (rwkv7.py:503-517, :561-563; chirrup/worker.py feeding the sampled id
+// back): as `tok < 0`, an index into the fed-back ids, a dtype copy, `where`, the embedding gather and the zeroing of the
+// launch-sync words they were SIX launches of ~4.8 us in front of every step, and `state[2] += T` over a slot list three behind it.
+namespace {
+// x[row] = emb[token]; token = tokens[row], or feedback[slot of the row's sequence] when tokens[row] < 0 (the id the sampler left
+// there one step ago -- never seen by the host).  One workgroup per row, 16 B per lane per trip.  Workgroup 0 also zeroes
+// `zero_words` (the launch-sync words of this stream: tile counters and time-mix hand-off words).
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int T, const int C, const int V, const f16 *__restrict__ emb,
+                                                         const int64_t *__restrict__ tokens, const int32_t *__restrict__ slot_idx,
+                                                         const int32_t *__restrict__ feedback, f16 *__restrict__ x,
+                                                         int32_t *__restrict__ zero_words, const int n_zero,
+                                                         const int32_t *__restrict__ elapsed_pool, int32_t *__restrict__ elapsed_rows) {
+    const int row = blockIdx.x;
+    if (row == 0)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0;
+    const int b = row / T;
+    const int slot = slot_idx ? slot_idx[b] : b;
+    if (elapsed_rows && row == b * T && threadIdx.x == 0) elapsed_rows[b] = elapsed_pool[slot];      // the slot table's counters, by row
+    int64_t tok = tokens[row];
+    if (tok < 0 && feedback) tok = feedback[slot];
+    const bool ok = tok >= 0 && tok < V;               // (an id outside the table: a zero row instead of a wild read)
+    const f16x8 *src = reinterpret_cast<const f16x8 *>(emb + (ok ? tok : 0) * (int64_t)C);
+    f16x8 *dst = reinterpret_cast<f16x8 *>(x + (int64_t)row * C);
+    for (int c = threadIdx.x; c < (C >> 3); c += 256) dst[c] = ok ? src[c] : f16x8{};
+}
+
+__global__ __launch_bounds__(256) void advance_elapsed_kernel(const int B, const int T, const int32_t *__restrict__ slot_idx,
+                                                              int32_t *__restrict__ elapsed) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) elapsed[slot_idx ? slot_idx[b] : b] += T;
+}
+}  // namespace
+
+extern "C" int rwkv7_embed_rows(int B, int T, int C, int V, const void *emb, const int64_t *tokens, const int32_t *slot_idx,
+                                const int32_t *feedback, void *x, int32_t *zero_words, int n_zero, const int32_t *elapsed_pool,
+                                int32_t *elapsed_rows, void *stream) {
+    if (B <= 0 || T <= 0 || C <= 0 || (C & 7) || V <= 0 || n_zero < 0) return CHIRRUP_E_SHAPE;
+    if (!emb || !tokens || !x || (n_zero && !zero_words) || (elapsed_rows && !elapsed_pool)) return CHIRRUP_E_NULL;
+    if (mis16(emb) || mis16(x)) return CHIRRUP_E_ALIGN;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)(B * T)), dim3(256), 0, static_cast<hipStream_t>(stream), T, C, V,
+                       static_cast<const f16 *>(emb), tokens, slot_idx, feedback, static_cast<f16 *>(x), zero_words, n_zero, elapsed_pool,
+                       elapsed_rows);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_advance_elapsed(int B, int T, const int32_t *slot_idx, int32_t *elapsed, void *stream) {
+    if (B <= 0 || T <= 0) return CHIRRUP_E_SHAPE;
+    if (!elapsed) return CHIRRUP_E_NULL;
+    hipLaunchKernelGGL(advance_elapsed_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), B, T,
+                       slot_idx, elapsed);
+    return (int)hipGetLastError();
+}

@@ -109,27 +109,32 @@ PAIR_REDUCE = True         # False: 2-way splits always go through the reduce la
 _sync_backing = {}
 
 
-def _sync_arena(device):
-    """(tile counters, time-mix hand-off words) of the current stream: two views of ONE zero-initialised int32 tensor per device
-    and stream, so that a decode graph zeroes both with one fill node (reset_launch_sync).  Returns (backing, created)."""
+def _sync_arena(device, will_zero: bool = False):
+    """(tile counters, time-mix hand-off words) of the current stream: two views of ONE int32 tensor per device and stream, so
+    that a decode graph zeroes both at once.  Returns (backing, zeroed).  Created zero-filled -- except when the caller is about
+    to zero it anyway (will_zero) while the stream is capturing: torch.zeros there would put a fill node of its own into the graph
+    (round 3's graphs carried four fills: each buffer's allocation-time fill besides its reset)."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     b = _sync_backing.get(key)
     if b is not None:
         return b, False
     L = _lib.load()
     n_pair = (L.skinny_gemm_pair_counters() + 63) // 64 * 64
-    b = _sync_backing[key] = torch.zeros(n_pair + L.rwkv7_tmix_sync_words() + 2, dtype=torch.int32, device=device)
+    n = n_pair + L.rwkv7_tmix_sync_words() + 2
+    lazy = will_zero and device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    b = torch.empty(n, dtype=torch.int32, device=device) if lazy else torch.zeros(n, dtype=torch.int32, device=device)
+    _sync_backing[key] = b
     _pair_counters[key] = b[:L.skinny_gemm_pair_counters()]
     _chain_sync[key] = b[n_pair:]
-    return b, True
+    return b, not lazy
 
 
 def reset_launch_sync(device=None) -> None:
     """Zero the tile counters AND the time-mix hand-off words of the current stream with one fill (a single node at the head of
-    a captured decode graph; round 3's graphs carried four: each buffer's allocation-time fill was captured besides its reset)."""
+    a captured decode graph)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    b, created = _sync_arena(dev)
-    if not created:
+    b, zeroed = _sync_arena(dev, will_zero=True)
+    if not zeroed:
         b.zero_()
 
 
@@ -452,6 +457,46 @@ def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=
                                            _ptr(frequency_penalty), _ptr(slot_idx), _ptr(out), _stream())
     _lib.check(rc, "rwkv7_penalize_argmax")
     return out
+
+
+def embed_rows(emb, tokens, slot_idx=None, feedback=None, zero_sync: bool = False, elapsed_pool=None):
+    """x [B,T,C] = emb[tokens] in ONE launch (include/chirrup_amd.h: rwkv7_embed_rows).  tokens int64 [B,T] on the device; a
+    negative token takes feedback[slot of its row] (int32 [n_slots]).  zero_sync: the same launch zeroes the current stream's
+    launch-sync words (what reset_launch_sync does with a fill node).  elapsed_pool (int32 [n_slots], with slot_idx): also returns
+    the slots' step counters in batch-row order.  Returns x, or (x, elapsed_rows)."""
+    if not emb.is_cuda or emb.dtype != torch.float16 or emb.dim() != 2 or not emb.is_contiguous():
+        raise _lib.ChirrupAmdError("emb: expected contiguous GPU fp16 [V,C]")
+    if not tokens.is_cuda or tokens.dtype != torch.int64 or tokens.dim() != 2 or not tokens.is_contiguous():
+        raise _lib.ChirrupAmdError("tokens: expected contiguous GPU int64 [B,T]")
+    B, T = tokens.shape
+    V, C = emb.shape
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    if feedback is not None:
+        _chk(feedback, "feedback", torch.int32)
+    x = torch.empty((B, T, C), dtype=torch.float16, device=emb.device)
+    zw, nz = None, 0
+    if zero_sync:
+        zw, _zeroed = _sync_arena(emb.device, will_zero=True)
+        nz = zw.numel()
+    rows = None
+    if elapsed_pool is not None:
+        _chk(elapsed_pool, "elapsed_pool", torch.int32)
+        rows = torch.empty((B,), dtype=torch.int32, device=emb.device)
+    rc = _lib.load().rwkv7_embed_rows(B, T, C, V, _ptr(emb), _ptr(tokens), _ptr(slot_idx), _ptr(feedback), _ptr(x), _ptr(zw), nz,
+                                      _ptr(elapsed_pool), _ptr(rows), _stream())
+    _lib.check(rc, "rwkv7_embed_rows")
+    return x if rows is None else (x, rows)
+
+
+def advance_elapsed(elapsed, T: int, slot_idx=None) -> None:
+    """elapsed[slot_idx[b]] += T (elapsed[b] without slot_idx), one launch (rwkv7.py:561-563 `state[2] += T` over a slot list)."""
+    _chk(elapsed, "elapsed", torch.int32)
+    B = elapsed.numel() if slot_idx is None else slot_idx.numel()
+    if slot_idx is not None:
+        _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    rc = _lib.load().rwkv7_advance_elapsed(B, T, _ptr(slot_idx), _ptr(elapsed), _stream())
+    _lib.check(rc, "rwkv7_advance_elapsed")
 
 
 def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence) -> None:

@@ -487,14 +487,17 @@ class RWKV_x070:
         return self.forward_seq_batch(idxs, state, full_output)
 
     # ------------------------------------------------------------------ implementation
-    def _forward_tokens(self, idxs, state, full_output):
+    def _forward_tokens(self, idxs, state, full_output, zero_sync: bool = False):
         if isinstance(idxs, torch.Tensor):          # [B,T] int64 already on the device (graph path)
             tok = idxs
         else:
             lens = {len(t) for t in idxs}
             assert len(lens) == 1, "here all sequences must have the same length"   # rwkv7.py:284
             tok = torch.tensor(idxs, device=self.device, dtype=torch.long)
-        x = self.z["emb.weight"][tok]                                            # [B,T,C]
+        if self.fused and tok.is_cuda:
+            x = ops.embed_rows(self.z["emb.weight"], tok.contiguous(), zero_sync=zero_sync)   # [B,T,C]; (+ the launch-sync words zeroed)
+        else:
+            x = self.z["emb.weight"][tok]                                        # [B,T,C]
         return self._forward_embedded(x, state, tok.shape[1], full_output)
 
     def capture_decode_graph(self, state, warmup: int = 2):
@@ -523,7 +526,7 @@ class RWKV_x070:
         x = F.layer_norm(x, (self.n_embd,), weight=z["ln_out.weight"], bias=z["ln_out.bias"])
         return F.linear(x, z["head.weight"])
 
-    def forward_slots(self, idxs, pool, slot_idx: torch.Tensor, full_output: bool = False):
+    def forward_slots(self, idxs, pool, slot_idx: torch.Tensor, full_output: bool = False, feedback=None, zero_sync: bool = False):
         """State-pool form of forward_seq_batch_seperate (not in the reference): ``pool`` is the
         worker's WHOLE slot table [fp16[L,2,n,C], fp16[L,n,H,64,64], int32[n]] and batch row b lives
         in slot ``slot_idx[b]`` (int32 [B] on the device, all distinct).  Nothing is gathered or
@@ -535,10 +538,12 @@ class RWKV_x070:
         else:
             assert len({len(t) for t in idxs}) == 1, "here all sequences must have the same length"
             tok = torch.tensor(idxs, device=self.device, dtype=torch.long)
-        x = self.z["emb.weight"][tok]
-        return self._forward_embedded_fused(x, pool, tok.shape[1], full_output, slot_idx=slot_idx)
+        # one launch: the embedding rows (a negative token takes feedback[its slot], the id the sampler left there), the slots'
+        # step counters in row order and, for a decode graph, the zeroing of the stream's launch-sync words
+        x, elapsed_rows = ops.embed_rows(self.z["emb.weight"], tok.contiguous(), slot_idx, feedback, zero_sync, elapsed_pool=pool[2])
+        return self._forward_embedded_fused(x, pool, tok.shape[1], full_output, slot_idx=slot_idx, elapsed_rows=elapsed_rows)
 
-    def _forward_embedded_fused(self, x, state, T, full_output, slot_idx=None):
+    def _forward_embedded_fused(self, x, state, T, full_output, slot_idx=None, elapsed_rows=None):
         """Same arithmetic as _forward_embedded with every element-wise chain in one HIP kernel
         (csrc/elementwise.hip, csrc/wkv7.hip) and, in the decode-batch regime (`hw` below), every projection of the
         layer through the MFMA ring GEMM (csrc/skinny_gemm.hip).  x [B,T,C] is consumed (updated in place as the
@@ -546,8 +551,10 @@ class RWKV_x070:
         z = self.z
         s0, s1, s2 = state
         if slot_idx is not None:
-            idx64 = slot_idx.long()
-            elapsed = s2.index_select(0, idx64)
+            # (idx64 is only needed by the T > 1 carry below; the slots' step counters come in batch-row order from the
+            # embedding launch when it ran, ops.embed_rows)
+            idx64 = slot_idx.long() if (T > 1 or elapsed_rows is None) else None
+            elapsed = elapsed_rows if elapsed_rows is not None else s2.index_select(0, idx64)
         else:
             idx64, elapsed = None, s2
         B, _, C = x.shape
@@ -816,7 +823,7 @@ class RWKV_x070:
         if not full_output:
             xo = xo.view(B, C)
         if slot_idx is not None:
-            s2.index_add_(0, idx64, torch.full((B,), T, dtype=s2.dtype, device=s2.device))
+            ops.advance_elapsed(s2, T, slot_idx)              # state[2] += T over the slot list, one launch
         if self.head8 is not None:
             return ops.mm8t_linear(xo.reshape(-1, C), *self.head8, tiled=self._head8_tiled).view(*xo.shape[:-1], -1)
         if (hw or not self.keep_row_major) and self.skinny_head and xo.shape[0] <= 256:
@@ -885,8 +892,9 @@ class DecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            ops.reset_launch_sync(model.device)           # one fill node: every replay starts from zeroed tile counters and hand-off words
-            self.logits = model.forward_seq_batch(self.tokens, state)
+            # the embedding launch at the head also zeroes the tile counters and hand-off words: every replay starts clean
+            self.logits = model._forward_tokens(self.tokens, state, False, zero_sync=True)
+            state[2] += 1
         torch.cuda.synchronize()
         for t, s in zip(state, snap):
             t.copy_(s)
@@ -916,10 +924,7 @@ class SlotDecodeGraph:
         self.slot_idx = torch.full((B,), parking_slot, dtype=torch.int32, device=dev)
 
         def fwd():
-            tok = self.tokens
-            if feedback is not None:
-                tok = torch.where(tok < 0, feedback[self.slot_idx.long()].long().view(B, 1), tok)
-            return model.forward_slots(tok, pool, self.slot_idx)
+            return model.forward_slots(self.tokens, pool, self.slot_idx, feedback=feedback, zero_sync=True)
 
         snap = [t.clone() for t in pool]
         side = torch.cuda.Stream(device=dev)
@@ -931,8 +936,7 @@ class SlotDecodeGraph:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            ops.reset_launch_sync(dev)                    # one fill node: every replay starts from zeroed tile counters and hand-off words
-            self.logits = fwd()
+            self.logits = fwd()                           # (its first launch zeroes the tile counters and hand-off words: every replay starts clean)
         torch.cuda.synchronize()
         for t, s_ in zip(pool, snap):
             t.copy_(s_)

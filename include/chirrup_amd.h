@@ -406,6 +406,19 @@ int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_i
                          const float *penalty_weight, float *alpha_presence, const float *presence, int64_t presence_stride,
                          void *stream);
 
+/* The two ends of a decode step around the layers (Albatross/rwkv7.py:503-517 `_pre`: the embedding gather; :561-563 `_post`:
+ * state[2] += T), each one launch.  rwkv7_embed_rows: x[b][t] = emb[token], token = tokens[b*T + t], or -- when that is negative and
+ * `feedback` is given -- feedback[slot_idx[b]] (feedback[b] without slot_idx): the id the sampler left for that slot one step ago
+ * (chirrup/worker.py:527: the reference round-trips it through the host).  emb binary16 [V][C], C % 8 == 0, x binary16 [B*T][C]; a
+ * token outside [0, V) gives a zero row.  zero_words / n_zero: int32 words zeroed by the same launch (the caller's launch-sync words:
+ * tile counters and time-mix hand-off words of the stream), or NULL / 0.  elapsed_rows (or NULL): elapsed_rows[b] = elapsed_pool[slot
+ * of row b] -- the slot table's step counters in batch-row order, as the WKV7 entries take them.
+ * rwkv7_advance_elapsed: elapsed[slot_idx[b]] += T for b < B (elapsed[b] without slot_idx; slots distinct). */
+int rwkv7_embed_rows(int B, int T, int C, int V, const void *emb, const int64_t *tokens, const int32_t *slot_idx,
+                     const int32_t *feedback, void *x, int32_t *zero_words, int n_zero, const int32_t *elapsed_pool,
+                     int32_t *elapsed_rows, void *stream);
+int rwkv7_advance_elapsed(int B, int T, const int32_t *slot_idx, int32_t *elapsed, void *stream);
+
 /*
  * Sort-free top-p / top-k / temperature sampling of n_rows rows of `logits` (binary16 [B][V], V <= 65536,
  * V % 8 == 0), row list `rows` (indices into logits / ids).  Semantics of

@@ -259,3 +259,42 @@ def test_mm8_chain_folded_into_neighbouring_kernels_equals_mm8t_linear(rows, C):
     dx = (x_f.float() - x2_ref.float()).abs()
     assert float(dx.max()) <= 4e-3 and float((dx > 0).float().mean()) < 0.10      # (the 1024*S0 term of the u8 offset makes delta that sensitive to the order of the S0 sum)
     assert float((out.float() - out_ref.float()).abs().max()) <= 8e-3
+
+
+@pytest.mark.parametrize("B,T,C,V", [(5, 1, 128, 1000), (3, 4, 768, 65536), (200, 1, 4096, 65536)])
+def test_embed_rows_and_advance_elapsed_equal_the_torch_ops(B, T, C, V):
+    """The two ends of a decode step as one launch each (include/chirrup_amd.h: rwkv7_embed_rows, rwkv7_advance_elapsed) against
+    the torch statements they replace: the embedding gather with fed-back ids for negative tokens (rwkv7.py:503-517 + the worker's
+    id feedback), the slots' step counters in row order, the zeroing of the launch-sync words, and state[2] += T over a slot list."""
+    from chirrup_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(B + T + C)
+    dev = "cuda"
+    emb = torch.randn(V, C, generator=g).half().to(dev)
+    n_slots = B + 7
+    slots = torch.randperm(n_slots, generator=g)[:B].to(torch.int32).to(dev)
+    tokens = torch.randint(0, V, (B, T), generator=g).to(dev)
+    tokens[::2, 0] = -1                                    # these rows take the id fed back for their slot
+    feedback = torch.randint(0, V, (n_slots,), generator=g).to(torch.int32).to(dev)
+    pool = torch.randint(0, 1000, (n_slots,), generator=g).to(torch.int32).to(dev)
+    arena, _ = ops._sync_arena(emb.device)
+    arena.fill_(7)
+    x, rows = ops.embed_rows(emb, tokens, slots, feedback, zero_sync=True, elapsed_pool=pool)
+    want_tok = torch.where(tokens < 0, feedback[slots.long()].long().view(B, 1), tokens)
+    assert torch.equal(x.view(torch.int16), emb[want_tok].view(torch.int16))
+    assert torch.equal(rows, pool[slots.long()])
+    assert int(arena.abs().sum()) == 0
+    # without slots / feedback / extras: the plain gather; an id outside the table gives a zero row
+    tok2 = torch.randint(0, V, (B, T), generator=g).to(dev)
+    assert torch.equal(ops.embed_rows(emb, tok2).view(torch.int16), emb[tok2].view(torch.int16))
+    tok2[0, 0] = V + 5
+    assert float(ops.embed_rows(emb, tok2)[0, 0].abs().max()) == 0.0
+    # state[2] += T
+    before = pool.clone()
+    ops.advance_elapsed(pool, T, slots)
+    want = before.clone()
+    want[slots.long()] += T
+    assert torch.equal(pool, want)
+    flat = torch.arange(B, dtype=torch.int32, device=dev)
+    ops.advance_elapsed(flat, 3)
+    assert torch.equal(flat, torch.arange(B, dtype=torch.int32, device=dev) + 3)
