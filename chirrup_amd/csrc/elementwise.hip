@@ -648,3 +648,25 @@ extern "C" int rwkv7_advance_elapsed(int B, int T, const int32_t *slot_idx, int3
                        slot_idx, elapsed);
     return (int)hipGetLastError();
 }
+
+// dst[slot][:] = src[slot][:] for the slots of a batch (binary16 rows of C channels): the token-shift carry of a chunk of T > 1
+// tokens goes to a side table first (rows of one launch race on the carry, see rwkv7_add_ln_mix) and is committed per slot
+// afterwards -- as torch ops an index_select and an index_copy_ per commit, two commits per layer.
+namespace {
+__global__ __launch_bounds__(256) void copy_slot_rows_kernel(const int C, const int32_t *__restrict__ slot_idx, const f16 *__restrict__ src,
+                                                             f16 *__restrict__ dst) {
+    const int64_t off = (int64_t)slot_idx[blockIdx.x] * C;
+    const f16x8 *s = reinterpret_cast<const f16x8 *>(src + off);
+    f16x8 *d = reinterpret_cast<f16x8 *>(dst + off);
+    for (int c = threadIdx.x; c < (C >> 3); c += 256) d[c] = s[c];
+}
+}  // namespace
+
+extern "C" int rwkv7_copy_slot_rows(int B, int C, const int32_t *slot_idx, const void *src, void *dst, void *stream) {
+    if (B <= 0 || C <= 0 || (C & 7)) return CHIRRUP_E_SHAPE;
+    if (!slot_idx || !src || !dst) return CHIRRUP_E_NULL;
+    if (mis16(src) || mis16(dst)) return CHIRRUP_E_ALIGN;
+    hipLaunchKernelGGL(copy_slot_rows_kernel, dim3((unsigned)B), dim3(256), 0, static_cast<hipStream_t>(stream), C, slot_idx,
+                       static_cast<const f16 *>(src), static_cast<f16 *>(dst));
+    return (int)hipGetLastError();
+}

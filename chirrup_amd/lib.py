@@ -59,6 +59,7 @@ SIGNATURES = {
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "rwkv7_embed_rows": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _vp]),
     "rwkv7_advance_elapsed": (_i, [_i, _i, _vp, _vp, _vp]),
+    "rwkv7_copy_slot_rows": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
     "skinny_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "skinny_gemm_splits": (_i, [_i, _i, _i, _i]),
     "skinny_gemm_batched_workspace_bytes": (_i64, [_i, _i, _i, _i, _i]),

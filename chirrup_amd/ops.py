@@ -499,6 +499,16 @@ def advance_elapsed(elapsed, T: int, slot_idx=None) -> None:
     _lib.check(rc, "rwkv7_advance_elapsed")
 
 
+def copy_slot_rows(src, dst, slot_idx) -> None:
+    """dst[slot] = src[slot] for the slots of a batch, one launch (include/chirrup_amd.h: rwkv7_copy_slot_rows); fp16 [n_slots, C]."""
+    _chk(src, "src", torch.float16), _chk(dst, "dst", torch.float16, tuple(src.shape))
+    if src.dim() != 2:
+        raise _lib.ChirrupAmdError("copy_slot_rows: expected [n_slots, C] tables")
+    _chk(slot_idx, "slot_idx", torch.int32)
+    rc = _lib.load().rwkv7_copy_slot_rows(slot_idx.numel(), src.shape[1], _ptr(slot_idx), _ptr(src), _ptr(dst), _stream())
+    _lib.check(rc, "rwkv7_copy_slot_rows")
+
+
 def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence) -> None:
     """ONE launch for what sampling `ids` (int32 [n]) for the slots `slot_idx` (int32 [n] or None) changes on the device
     (chirrup/worker.py:527-535): last_ids[slot] = id, occurrence[slot, id] += penalty_weight[id], alpha_presence[slot, id] =

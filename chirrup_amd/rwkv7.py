@@ -551,12 +551,10 @@ class RWKV_x070:
         z = self.z
         s0, s1, s2 = state
         if slot_idx is not None:
-            # (idx64 is only needed by the T > 1 carry below; the slots' step counters come in batch-row order from the
-            # embedding launch when it ran, ops.embed_rows)
-            idx64 = slot_idx.long() if (T > 1 or elapsed_rows is None) else None
-            elapsed = elapsed_rows if elapsed_rows is not None else s2.index_select(0, idx64)
+            # (the slots' step counters come in batch-row order from the embedding launch when it ran, ops.embed_rows)
+            elapsed = elapsed_rows if elapsed_rows is not None else s2.index_select(0, slot_idx.long())
         else:
-            idx64, elapsed = None, s2
+            elapsed = s2
         B, _, C = x.shape
         H, rows, dev = self.n_head, B * T, x.device
         x = x.contiguous()
@@ -612,7 +610,7 @@ class RWKV_x070:
             if slot_idx is None:
                 prev.copy_(carry)
             else:
-                prev.index_copy_(0, idx64, carry.index_select(0, idx64))
+                ops.copy_slot_rows(carry, prev, slot_idx)          # (one launch; as torch ops an index_select + an index_copy_)
 
         for i, lw in enumerate(self._layers):
             for j in (0, 1):

@@ -418,6 +418,9 @@ int rwkv7_embed_rows(int B, int T, int C, int V, const void *emb, const int64_t 
                      const int32_t *feedback, void *x, int32_t *zero_words, int n_zero, const int32_t *elapsed_pool,
                      int32_t *elapsed_rows, void *stream);
 int rwkv7_advance_elapsed(int B, int T, const int32_t *slot_idx, int32_t *elapsed, void *stream);
+/* dst[slot_idx[b]][0..C) = src[slot_idx[b]][0..C) for b < B: binary16 tables [n_slots][C] (C % 8 == 0, slots distinct) -- the commit of
+ * a chunk's token-shift carry into the slot table (the T > 1 form of rwkv7_add_ln_mix writes the carry to a side table). */
+int rwkv7_copy_slot_rows(int B, int C, const int32_t *slot_idx, const void *src, void *dst, void *stream);
 
 /*
  * Sort-free top-p / top-k / temperature sampling of n_rows rows of `logits` (binary16 [B][V], V <= 65536,

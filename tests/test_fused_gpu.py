@@ -298,3 +298,17 @@ def test_embed_rows_and_advance_elapsed_equal_the_torch_ops(B, T, C, V):
     flat = torch.arange(B, dtype=torch.int32, device=dev)
     ops.advance_elapsed(flat, 3)
     assert torch.equal(flat, torch.arange(B, dtype=torch.int32, device=dev) + 3)
+
+
+def test_copy_slot_rows_equals_index_copy():
+    from chirrup_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for n_slots, B, C in ((9, 4, 128), (201, 200, 4096)):
+        src = torch.randn(n_slots, C, generator=g).half().cuda()
+        dst = torch.randn(n_slots, C, generator=g).half().cuda()
+        slots = torch.randperm(n_slots, generator=g)[:B].to(torch.int32).cuda()
+        want = dst.clone()
+        want.index_copy_(0, slots.long(), src.index_select(0, slots.long()))
+        ops.copy_slot_rows(src, dst, slots)
+        assert torch.equal(dst.view(torch.int16), want.view(torch.int16))
