@@ -216,6 +216,9 @@ class _LazyWeights(dict):
         return list(dict.keys(self)) + list(self._lazy.keys())
 
 
+_TORCH_CARRY = bool(os.environ.get("CHIRRUP_TORCH_CARRY"))
+
+
 class RWKV_x070:
     """See module docstring.  ``wkv_impl`` is a test hook (signature of ops.forward_seq); the
     default is the HIP kernel and nothing else is ever selected automatically."""
@@ -610,7 +613,11 @@ class RWKV_x070:
             if slot_idx is None:
                 prev.copy_(carry)
             else:
-                ops.copy_slot_rows(carry, prev, slot_idx)          # (one launch; as torch ops an index_select + an index_copy_)
+                if _TORCH_CARRY:                                   # (A/B switch CHIRRUP_TORCH_CARRY=1: the torch ops this replaced)
+                    i64 = slot_idx.long()
+                    prev.index_copy_(0, i64, carry.index_select(0, i64))
+                else:
+                    ops.copy_slot_rows(carry, prev, slot_idx)      # one launch
 
         for i, lw in enumerate(self._layers):
             for j in (0, 1):
