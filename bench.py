@@ -82,7 +82,78 @@ def parse():
     p.add_argument("--skinny-rkv", type=int, default=None, help="1/0: r/k/v projections through the hand-written GEMM, A/B only")
     p.add_argument("--cpu-layers", type=int, default=12, help="layers of the model the CPU baseline times")
     p.add_argument("--repeats", type=int, default=10, help="further timed regions of --steps steps after the contract's one (ms_per_step_median)")
+    p.add_argument("--rehearse-launch", action="store_true",
+                   help="launch protocol only (fan-out, rendezvous, barrier + max-over-ranks timing of a sleeping step, rank 0's JSON line): "
+                        "no model, no GPU call -- the CPU rehearsal of --gpus N (tests/test_multiproc_cpu.py); its line is not a measurement")
     return p.parse_args()
+
+
+def fan_out(a):
+    """`python bench.py --gpus N` without a launcher: this process becomes the launcher.  It starts N children -- the same command
+    line with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, one worker process per GPU, the layout of
+    the reference's spawn loop (chirrup/engine_core.py:135-153: worker k <-> gpu_id=[k]) -- BEFORE it has made any GPU call (it
+    never makes one: no exec from a GPU process, no second HIP context beside the ranks'), relays rank 0's stdout (the one JSON
+    line) and every rank's stderr, and exits non-zero when any child does.  Returns the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CHIRRUP_BENCH_FANNED_OUT="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))   # ranks > 0 have no business on stdout
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * a.gpus
+    while any(c is None for c in codes):
+        for r, p_ in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p_.poll()
+        if any(c not in (None, 0) for c in codes):      # a rank died: the others would wait in a barrier for ever -- end them (exact PIDs)
+            for r, p_ in enumerate(procs):
+                if codes[r] is None:
+                    p_.terminate()
+            for r, p_ in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p_.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p_.kill()
+                        codes[r] = p_.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(chunks).decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py --gpus {a.gpus}: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def rehearse_launch(a, world, rank):
+    """--rehearse-launch: everything of a multi-rank run except the model (see the flag's help)."""
+    from chirrup_amd.dist_util import gather_floats, timed_region
+
+    dev = torch.device("cpu")
+    dt = timed_region(lambda: time.sleep(0.002 * (rank + 1)), a.steps, dev)
+    from chirrup_amd import dist_util
+    per_rank = gather_floats(dist_util.LAST_LOCAL_SECONDS / a.steps * 1e3, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "launch rehearsal (no model, no compute; not a measurement)", "value": None, "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+                          "world_size_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                          "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "per_rank_ms_per_step": [round(x, 4) for x in per_rank]}), flush=True)
 
 
 def build_model(name, device, fused, mm8=False, tiled=True, min_embd=None, att8=False):
@@ -491,6 +562,8 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None, repeats=0):
     for _ in range(warmup):
         timed_step()
     dt = timed_region(timed_step, steps, dev)               # barrier + sync on both sides, max over ranks: THE contract's region
+    from chirrup_amd import dist_util as _du
+    a._local_dt = _du.LAST_LOCAL_SECONDS                    # this rank's own time of that region
     # the same region repeated (boxes and runs differ by more than a round's gains; the median of >= 10 regions is what to compare)
     a._regions = [timed_region(timed_step, steps, dev) for _ in range(repeats)]
     return dt, state
@@ -536,9 +609,22 @@ def engine_iterations(model, B, a, dev, rank, steps):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(fan_out(a))                     # before ANY GPU call of this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree"
+    if a.rehearse_launch:
+        if os.environ.get("CHIRRUP_BENCH_REHEARSE_FAIL_RANK") == str(rank):     # the test of the launcher's failure path
+            sys.exit(3)
+        if world > 1:
+            dist.init_process_group(os.environ.get("CHIRRUP_BENCH_BACKEND", "gloo"))
+        rehearse_launch(a, world, rank)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback in the product path)"
     local = local % max(1, torch.cuda.device_count())    # (rehearsals put several ranks on one GPU)
     torch.cuda.set_device(local)
@@ -562,7 +648,6 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from chirrup_amd.synth import CONFIGS
 
@@ -612,6 +697,8 @@ def main():
         model.skinny_lora_up = bool(a.skinny_lora_up)
     dt, state = timed_decode(model, B, a, dev, rank, repeats=a.repeats)
     regions = sorted(r / a.steps * 1e3 for r in a._regions)
+    from chirrup_amd.dist_util import gather_floats
+    per_rank_ms = gather_floats(a._local_dt / a.steps * 1e3, dev)       # (a collective: every rank calls it)
 
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
@@ -664,6 +751,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if not (a.mm8 or a.mm8_all) else ("f16 (u8 ffn weights, mm8)" if not a.mm8_all else "f16 (u8 weights for R/K/V/O, ffn and head: mm8)"), "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
+            "world_size_seen": dist.get_world_size() if grouped else 1,
+            "collective_backend": (dist.get_backend() if grouped else None),
+            "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
             "config": {"workload": f"RWKV7-g1 {a.model} (L={L}, C={C}, V=65536), worker_num={world}, bsz={B}/worker, "
                                    "greedy decode step incl. " + ("plain arg-max" if a.no_penalties else "the worker's penalty tables, fused arg-max and device-side id commit") + " and token-id D2H" + (" (blocking)" if a.sync_ids else " (consumed one step behind, as Worker(run_ahead=True))") + "; random-init weights",
                        "global_batch": world * B, "parallelism": f"replicas x{world} (no collective)",

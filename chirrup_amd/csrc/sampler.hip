@@ -121,8 +121,11 @@ __global__ __launch_bounds__(256) void commit_sampled_kernel(const int n, const 
                                                              const int32_t *__restrict__ slot_idx, int32_t *__restrict__ last_ids,
                                                              float *__restrict__ occurrence, const float *__restrict__ penalty_weight,
                                                              float *__restrict__ alpha, const float *__restrict__ presence,
-                                                             const int64_t presence_stride) {
+                                                             const int64_t presence_stride, const int32_t *__restrict__ status_src,
+                                                             int32_t *__restrict__ status_dst) {
     const int row = blockIdx.x * 256 + threadIdx.x;
+    // the launch-status word of the step that produced these ids travels to the host behind them (one D2H copy for both)
+    if (row == 0 && status_dst) *status_dst = status_src ? __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     if (row >= n) return;
     const int id = ids[row];
     const int64_t slot = slot_idx ? (int64_t)slot_idx[row] : (int64_t)row;
@@ -135,11 +138,11 @@ __global__ __launch_bounds__(256) void commit_sampled_kernel(const int n, const 
 
 extern "C" int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
                                     const float *penalty_weight, float *alpha_presence, const float *presence,
-                                    int64_t presence_stride, void *stream) {
+                                    int64_t presence_stride, const int32_t *status_src, int32_t *status_dst, void *stream) {
     if (n <= 0 || V <= 0 || presence_stride < 0) return CHIRRUP_E_SHAPE;
     if (!ids || !last_ids || !occurrence || !penalty_weight || !alpha_presence || !presence) return CHIRRUP_E_NULL;
     hipLaunchKernelGGL(commit_sampled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, V, ids,
-                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride);
+                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride, status_src, status_dst);
     return (int)hipGetLastError();
 }
 

@@ -824,7 +824,8 @@ __global__ __launch_bounds__(512) void ring_gemm_kernel(
 //       3. a `finished` ticket; the last chain workgroup zeroes the counters for the next launch.
 //   workgroups [n_chain, ...)  one R/K/V tile half each, exactly ring_gemm_kernel's EPI_F16 path; they never wait.
 // No workgroup waits for a higher-numbered one that could be undispatched behind it: the chain's producers ARE the lowest ids,
-// and every spin is bounded (status word set, outputs then undefined -- chirrup_amd checks it with the sampled ids).
+// and every spin is bounded (STICKY status word set, outputs then undefined -- chirrup_amd's worker receives the word with every
+// step's sampled ids: rwkv7_commit_sampled copies it behind them, the step that gave up is fatal).
 struct ChainTable {
     const f16 *dX[4];            // down-projection inputs  [M][ldx]
     const f16 *dW[4];            // down-projection weights [dN[p]][K], row stride ldw (rows >= dN read as zeros)
@@ -840,12 +841,16 @@ struct ChainTable {
     int halves;                  // 2: every tile as two workgroups over the two halves of the rows (M > 32); 1: whole rows
     int rkv_splits;              // halves == 1 only: K-slices of an R/K/V tile, reduced inside the launch by the last to arrive (EPI_PAIR)
     float *slab;                 // [down tile][half][slice][16 MT][128] binary32
-    int *sync;                   // kChainTickets tickets, then kChainDone done counters, then {finished, status}
+    int *sync;                   // kChainTickets tickets, kChainDone done counters, `finished`, kChainPairs R/K/V tile tickets, then the status word
+    int *status;                 // the sticky status word: the caller's own, or sync + kChainWords - 1
     int spin_limit;
     unsigned long long *stamps;  // diagnostic (skinny_gemm_clock_probe): 8 x 100-MHz time stamps per workgroup
 };
 constexpr int kChainTickets = 64, kChainDone = 8, kChainPairs = 512, kChainMaxSplits = 8;
-constexpr int kChainWords = kChainTickets + kChainDone + 2 + kChainPairs;     // ... then the R/K/V tiles' tickets (rkv_splits > 1)
+// The status word is the LAST word: everything in front of it may be zeroed between launches (a captured decode graph does so at
+// the head of every replay), the status word never is (round-3 advisor finding: it sat between `finished` and the pair tickets,
+// inside the range every replay zeroed, so a step that gave up was erased by the next one).
+constexpr int kChainWords = kChainTickets + kChainDone + 1 + kChainPairs + 1;
 
 // one K-range of one 128-column tile: prologue, main loop; leaves the sums in `acc` and EVERY wave behind a barrier (the
 // ring is free again).  Loader waves come back too (ring_gemm_kernel's leave at this point).  D: ring slots.
@@ -932,7 +937,7 @@ __device__ __forceinline__ bool chain_wait(int *word, const int want, const int 
         if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
         __builtin_amdgcn_s_sleep(8);
     }
-    __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_or(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: only ever OR-ed by launches
     return false;
 }
 
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
             e8.rx = ct.m_rx[b], e8.mx = ct.m_mx[b], e8.S = ct.m_S[b], e8.S_parts = 1;
             store_staged_mm8<256>(stg, t.M, n_base, t, e8);
         } else if (ct.rkv_splits > 1) {                       // ring_gemm_kernel's EPI_PAIR epilogue (same hand-off, same bits as a reduce launch)
-            int *const pair = ct.sync + kChainTickets + kChainDone + 2 + t.pair_id;
+            int *const pair = ct.sync + kChainTickets + kChainDone + 1 + t.pair_id;
             store_staged_sc1<256>(stg, t.M, n_base, t, t.kslice);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1008,7 +1013,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
 
     // ---- a chain workgroup
     int *const tickets = ct.sync, *const done = ct.sync + kChainTickets, *const finished = ct.sync + kChainTickets + kChainDone;
-    int *const status = finished + 1;
+    int *const status = ct.status;
     const int n_dtiles = ct.dfirst[ct.n_lora];
     unsigned long long *const stamps = ct.stamps ? ct.stamps + (int64_t)L * 8 : nullptr;
     auto stamp = [&](int i) {
@@ -1163,7 +1168,7 @@ __global__ __launch_bounds__(512) void chain_gemm_kernel(const int M, const int 
         }
         stamp(6);
     }
-    if (warm == 0x9e3779b9u && (uint32_t)tid == 511u + warm) __hip_atomic_store(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (never: keeps the warm-up loads)
+    if (warm == 0x9e3779b9u && (uint32_t)tid == 511u + warm) __hip_atomic_fetch_or(status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (never: keeps the warm-up loads)
     // 3. the last chain workgroup to finish leaves every counter at zero for the next launch
     stamp(7);
     if (tid == 0) {
@@ -1927,10 +1932,12 @@ extern "C" int skinny_gemm_f16_group(int count, const chirrup_gemm_problem *prob
 // 128-row tile read as zeros); wu_p tile images of [up_n][up_kimg] (k_up_p <= up_kimg, both % 64 == 0; up_n % 128 == 0).
 // workspace: rwkv7_tmix_gemms_workspace_bytes(...) bytes of hipMalloc'ed memory; sync: rwkv7_tmix_sync_words() ints, ZERO before the
 // first use, zero again after every completed launch (a launch that did not complete: zero them yourself); used by one
-// launch at a time.  sync[rwkv7_tmix_status_word()] is a STATUS word: non-zero after a launch whose bounded waits gave up
-// (another tenant holding most of the chip for > spin budget): that launch's LoRA outputs are then undefined.
+// launch at a time.  The STATUS word (`status`, an int32 of the caller's; NULL: sync[rwkv7_tmix_status_word()], the LAST sync word) is
+// sticky: launches only ever OR into it -- non-zero after a launch whose bounded waits gave up (another tenant holding most of
+// the chip for > spin budget): that launch's LoRA outputs are then undefined.  Words [0, rwkv7_tmix_status_word()) may be zeroed
+// between launches at any time; the status word is cleared by its owner only.
 extern "C" int rwkv7_tmix_sync_words(void) { return kChainWords; }
-extern "C" int rwkv7_tmix_status_word(void) { return kChainTickets + kChainDone + 1; }
+extern "C" int rwkv7_tmix_status_word(void) { return kChainWords - 1; }
 
 namespace {
 // K-slices per down-projection tile (half): as many as the idle CUs can take at once -- the chain's latency at <= 128 rows is
@@ -1976,10 +1983,28 @@ extern "C" int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, co
 }
 
 namespace {
+// compute units of the current device (256 on a whole MI355X; 32 on a CPX partition), cached per device ordinal
+int device_cus() {
+    static std::atomic<int> cus[32];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int n = cus[dev & 31].load(std::memory_order_acquire);
+    if (n <= 0) {
+        n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev & 31].store(n, std::memory_order_release);
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" int chirrup_device_cu_count(void) { return device_cus(); }
+
+namespace {
 // the launch behind rwkv7_tmix_gemms (binary16 main problems in gt) and rwkv7_tmix_gemms_mm8 (uint8: w8 = true, scales / row sums in m_*)
 int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, const f16 *const *m_rx, const f16 *const *m_mx,
                 const float *const *m_S, int n_lora, const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy,
-                int row_halves, void *workspace, void *sync, int spin_limit, void *stream) {
+                int row_halves, void *workspace, void *sync, void *status, int spin_limit, void *stream) {
     const int n_main = gt.used;
     if (n_lora <= 0 || n_lora > 4 || !lora) return CHIRRUP_E_SHAPE;
     if (M <= 0 || M > 256 || K <= 0 || (K % kKB) || ldx < K || ldw < K || (ldx & 7) || (ldw & (w8 ? 15 : 7))) return CHIRRUP_E_SHAPE;
@@ -2009,7 +2034,8 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
     const int MT = tiles_of(M, ct.halves == 2);
     if (n_dtiles * ct.halves > kChainTickets || gt.first[n_main] > kChainPairs) return CHIRRUP_E_UNSUPPORTED;
     const int main_wgs = (gt.first[n_main] * ct.halves * ct.rkv_splits + 15) / 16 * 16;   // whole runs of the XCD-aware tile order
-    const int spare = (256 - main_wgs) / 8 * 8;                      // every CU the R/K/V tiles leave idle
+    const int n_cus = device_cus();                                  // (round-3 advisor finding: 256 was hard-coded)
+    const int spare = n_cus > main_wgs ? (n_cus - main_wgs) / 8 * 8 : 0;      // every CU the R/K/V tiles leave idle
     ct.dsplits = chain_dsplits(K, n_dtiles * ct.halves, spare);
     // workspace: the down-projection slabs, then (split R/K/V) one run of partial planes per R/K/V problem
     unsigned char *ws = static_cast<unsigned char *>(workspace);
@@ -2021,10 +2047,15 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
             ws += ((int64_t)ct.rkv_splits * M * gt.N[i] * (int64_t)sizeof(float) + 255) / 256 * 256;
         }
     ct.sync = static_cast<int *>(sync);
+    ct.status = status ? static_cast<int *>(status) : ct.sync + kChainWords - 1;
     ct.n_chain = (n_dtiles * ct.halves * ct.dsplits + 7) / 8 * 8;   // the down-projection slices ... and every idle CU, for the up-projections
     static const int chain_max = [] { const char *e = getenv("CHIRRUP_CHAIN_MAX"); return e ? atoi(e) : 96; }();      // (tuning / A-B only)
     static const int chain_warm = [] { const char *e = getenv("CHIRRUP_CHAIN_WARM"); return e ? atoi(e) : 1; }();
     if (spare > ct.n_chain) ct.n_chain = spare < chain_max ? spare : (chain_max > ct.n_chain ? chain_max / 8 * 8 : ct.n_chain);
+    // chain workgroups wait for each other (a tile's slices, the up-projection shares for the hidden tiles): all of them must be
+    // resident at once, one per CU (160 KB of LDS each) -- on a CU-partitioned device they might not be: refuse, the caller has the
+    // two-launch form (skinny_gemm_f16_group + the batched up-projection launch)
+    if (ct.n_chain > n_cus) return CHIRRUP_E_UNSUPPORTED;
     ct.warm = chain_warm;
     ct.spin_limit = spin_limit > 0 ? spin_limit : 400000;          // x ~0.25 us of s_sleep: ~0.1 s
     const dim3 grid(ct.n_chain + main_wgs);
@@ -2067,7 +2098,7 @@ int tmix_launch(bool w8, int M, int K, int ldx, int64_t ldw, GroupTable &gt, con
 
 extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_p, int n_lora,
                                 const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
-                                void *workspace, void *sync, int spin_limit, void *stream) {
+                                void *workspace, void *sync, void *status, int spin_limit, void *stream) {
     if (n_main <= 0 || n_main > 4 || !main_p) return CHIRRUP_E_SHAPE;
     GroupTable gt{};
     gt.used = n_main;
@@ -2082,7 +2113,7 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
         gt.first[i + 1] = gt.first[i] + (q.n + kTileRows - 1) / kTileRows;
     }
     return tmix_launch(false, M, K, ldx, ldw, gt, nullptr, nullptr, nullptr, n_lora, lora, ld_hid, up_n, up_kimg, up_ldy, row_halves, workspace,
-                       sync, spin_limit, stream);
+                       sync, status, spin_limit, stream);
 }
 
 // The same launch with uint8 (mm8, w8a16) main problems: y = mm8(x, w) in the reference's split form -- xs = the activation
@@ -2092,7 +2123,7 @@ extern "C" int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, 
 // ldy % 8 == 0, 16-byte aligned y / rx / mx.  The LoRA problems stay binary16.
 extern "C" int rwkv7_tmix_gemms_mm8(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_mm8_problem *main_p, int n_lora,
                                     const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
-                                    void *workspace, void *sync, int spin_limit, void *stream) {
+                                    void *workspace, void *sync, void *status, int spin_limit, void *stream) {
     if (n_main <= 0 || n_main > 4 || !main_p) return CHIRRUP_E_SHAPE;
     GroupTable gt{};
     gt.used = n_main;
@@ -2110,7 +2141,7 @@ extern "C" int rwkv7_tmix_gemms_mm8(int M, int K, int ldx, int64_t ldw, int n_ma
         rx[i] = static_cast<const f16 *>(q.rx), mx[i] = static_cast<const f16 *>(q.mx), S[i] = q.S;
     }
     return tmix_launch(true, M, K, ldx, ldw, gt, rx, mx, S, n_lora, lora, ld_hid, up_n, up_kimg, up_ldy, row_halves, workspace, sync,
-                       spin_limit, stream);
+                       status, spin_limit, stream);
 }
 
 extern "C" int skinny_gemm_f16_partial(int M, int N, int K, const void *X, int ldx, const void *W, int64_t ldw, int w_tiled,

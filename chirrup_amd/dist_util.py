@@ -13,9 +13,24 @@ def shard_requests(n_requests: int, world: int, rank: int) -> List[int]:
     return list(range(rank, n_requests, world))
 
 
+LAST_LOCAL_SECONDS = 0.0      # this rank's own time of the last timed_region (before the max over ranks)
+
+
+def gather_floats(x: float, device: torch.device) -> List[float]:
+    """[x of rank 0, x of rank 1, ...] on every rank ([x] without a process group)."""
+    if not dist.is_initialized():
+        return [float(x)]
+    on_gpu = device.type == "cuda" and dist.get_backend() == "nccl"
+    t = torch.tensor([x], dtype=torch.float64, device=device if on_gpu else "cpu")
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def timed_region(fn: Callable[[], None], steps: int, device: torch.device) -> float:
     """barrier -> sync -> `steps` calls -> sync -> barrier; returns the MAX over ranks of the
     elapsed seconds (the driver's bench contract)."""
+    global LAST_LOCAL_SECONDS
     grouped = dist.is_initialized()          # also with a single rank: the same calls run whenever a group exists
     sync = (lambda: torch.cuda.synchronize(device)) if device.type == "cuda" else (lambda: None)
     if grouped:
@@ -25,6 +40,7 @@ def timed_region(fn: Callable[[], None], steps: int, device: torch.device) -> fl
     for _ in range(steps):
         fn()
     sync()
+    LAST_LOCAL_SECONDS = time.perf_counter() - t0
     if grouped:
         dist.barrier()
     dt = time.perf_counter() - t0

@@ -134,6 +134,17 @@ class AsyncEngineCore:
         for task in self._router.tasks_of(worker_id):
             self._router.finish_aborted(task)
         others = [w for w in self.workers if w.worker_id != worker_id and w.is_alive()]
+        if self.state_arena is not None:
+            # the worker's arena went with its process (round-3 advisor finding): its rows are dead in the engine's books
+            # (cache lookups drop them and the requests prefill again), the hits still queued for it complete as aborted
+            # (a hit carries only the tokens behind its prefix), and the surviving workers forget their views of its memory
+            self.state_arena.worker_dead(worker_id)
+            for tid in self.task_queue.drain_affinity(worker_id):
+                task = self._router.task(tid)
+                if task is not None:
+                    self._router.finish_aborted(task)
+            for w in others:
+                w.control_q.put({"type": "peer_dead", "worker": worker_id})
         if not others:
             for task in self._router.pending():
                 self._router.finish_aborted(task)
@@ -252,6 +263,19 @@ class AsyncEngineCore:
             for w in self.workers:
                 w.control_q.put({"type": "shutdown"})
                 w.abort_q.put(None)
+            if self.state_arena is not None:
+                # two phases: every worker first drops its views of the other workers' arenas ("peers_released"), only then
+                # may the owners of those arenas end (engine_process.worker_process_main)
+                import time
+
+                alive = {w.worker_id for w in self.workers if w.is_alive()}
+                t_end = time.time() + 15.0
+                with self._router.peers_released_cv:
+                    while not alive <= self._router.peers_released and time.time() < t_end:
+                        self._router.peers_released_cv.wait(timeout=0.2)
+                        alive = {w.worker_id for w in self.workers if w.is_alive()}
+                for w in self.workers:
+                    w.control_q.put({"type": "exit"})
             for w in self.workers:
                 w.process.join(timeout=10)
                 if w.process.is_alive():

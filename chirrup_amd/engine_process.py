@@ -52,20 +52,30 @@ def task_to_wire(task: Task) -> Dict[str, Any]:
 class ResultSink:
     """What a Task's ``output_queue`` is inside a worker process."""
 
-    def __init__(self, result_q, task_id: str, on_done=None, worker_id: Optional[str] = None, arena=None):
+    def __init__(self, result_q, task_id: str, on_done=None, worker_id: Optional[str] = None, arena=None, exports=None):
         self._q, self._id, self._on_done, self._wid, self._arena = result_q, task_id, on_done, worker_id, arena
+        self._exports = exports                         # the worker's PendingExports (device arenas)
 
     def put_nowait(self, msg):
         kind, payload = msg
         if kind == "task_completed":                    # the reference hands back the Task object: ship its final fields
             payload = {k: (int(getattr(payload, k)) if k == "request_status" else getattr(payload, k)) for k in _RESULT_FIELDS}
+            if self._exports is not None:
+                self._exports.flush(self._id)           # a row address must not arrive behind its request's completion
             if self._on_done is not None:
                 self._on_done(self._id)
         elif kind == "cache_prefill" and self._arena is not None and getattr(payload["state"], "arena", None) is self._arena:
             # exported straight into a row of THIS worker's arena: the row now belongs to whoever caches the prefix in the
-            # engine process (freed by an {"type": "arena_free"} control message); only its address leaves the process
+            # engine process (freed by an {"type": "arena_free"} control message); only its address leaves the process --
+            # and only once the copies into the row have COMPLETED: they are non-blocking copies on this worker's stream,
+            # behind its in-flight forward, and a peer worker reads the row on a stream of its own, in another process, with
+            # nothing to order the two (round-3 advisor finding).  Installs were event-gated already; exports are now too.
+            ev = self._arena.export_event(payload["state"].row) if hasattr(self._arena, "export_event") else None
             row = self._arena.adopt(payload["state"])
             payload = {"state": {WIRE_KEY: (self._wid, row)}, "prefilled_tokens": tuple(payload["prefilled_tokens"])}
+            if ev is not None and self._exports is not None and not ev.query():
+                self._exports.add(ev, self._id, (self._id, (kind, payload)))
+                return
         elif kind == "cache_prefill":
             st = payload["state"]
             if hasattr(st, "tensors"):
@@ -75,6 +85,39 @@ class ResultSink:
         elif kind == "token_generated" and len(payload) > 2:
             payload = (payload[0], payload[1], payload[2].detach().to("cpu"))
         self._q.put((self._id, (kind, payload)))
+
+
+class PendingExports:
+    """("cache_prefill", row address) messages whose device copies are still in flight: posted by the worker's loop
+    (``poll``, every iteration, like its pending installs) once their event has passed."""
+
+    def __init__(self, result_q):
+        self._q, self._items = result_q, []
+
+    def add(self, event, task_id: str, item) -> None:
+        self._items.append((event, task_id, item))
+
+    def poll(self) -> None:
+        if not self._items:
+            return
+        still = []
+        for ev, tid, item in self._items:
+            if ev.query():
+                self._q.put(item)
+            else:
+                still.append((ev, tid, item))
+        self._items = still
+
+    def flush(self, task_id: Optional[str] = None) -> None:
+        """Wait out and post the exports of one task (all tasks: None) -- at the task's completion and at shutdown."""
+        keep = []
+        for ev, tid, item in self._items:
+            if task_id is None or tid == task_id:
+                ev.synchronize()
+                self._q.put(item)
+            else:
+                keep.append((ev, tid, item))
+        self._items = keep
 
 
 class WorkerEventSink:
@@ -105,6 +148,7 @@ class RemoteTaskQueue:
         self._q, self._result_q, self._wid, self._steal = task_q, result_q, worker_id, steal
         self._affinity = dict(affinity_qs or {})        # worker id -> queue of hits on rows of that worker's arena
         self.arena = None                               # set by the worker once it has built its arena
+        self.exports = PendingExports(result_q)         # row addresses whose export copies are still in flight
         self.local_events: Dict[str, queue.Queue] = {}
         self._early_aborts: "OrderedDict[str, None]" = OrderedDict()
         self._lock = threading.Lock()
@@ -130,6 +174,9 @@ class RemoteTaskQueue:
                     pass
         raise queue.Empty
 
+    def poll_exports(self) -> None:
+        self.exports.poll()
+
     def installed(self, task_id: str, peer: bool) -> None:
         """The copy of an arena row into this worker's slot has completed: the engine may let the row go."""
         self._result_q.put((task_id, ("__installed__", {"peer": bool(peer), "worker": self._wid})))
@@ -145,7 +192,8 @@ class RemoteTaskQueue:
             if self._early_aborts.pop(d["task_id"], 0) is None:
                 ev.put_nowait(("abort", None))
         self._result_q.put((d["task_id"], ("__accepted__", self._wid)))
-        return Task(output_queue=ResultSink(self._result_q, d["task_id"], on_done=self.forget, worker_id=self._wid, arena=self.arena),
+        return Task(output_queue=ResultSink(self._result_q, d["task_id"], on_done=self.forget, worker_id=self._wid, arena=self.arena,
+                                            exports=self.exports),
                     task_event_queue=ev, **d)
 
     def deliver_abort(self, task_id: str) -> None:
@@ -183,6 +231,7 @@ def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLo
             tasks.deliver_abort(tid)
 
     threading.Thread(target=listen, daemon=True, name=f"chirrup:{worker_id}:aborts").start()
+    peers = worker_kwargs.get("peer_arenas")
     try:                                                # construction included: an exception there must reach the engine too
         kw = dict(worker_id=worker_id, gpu_id=gpu_id, model_config=model_config, task_queue=tasks,
                   master_event_queue=ControlQueue(control_q), worker_event_queue=WorkerEventSink(result_q), batch_size=batch_size)
@@ -199,6 +248,30 @@ def worker_process_main(worker_id: str, gpu_id: List[int], model_config: ModelLo
         result_q.put(("__worker_event__", (worker_id, "worker_error", {"error": f"{type(e).__name__}: {e}"})))
         raise
     finally:
+        # Shutdown order: a worker drops the views it has opened of the OTHER workers' arenas and says so;
+        # it ends -- and its own arena's memory with it -- only when the engine has heard that from every worker (an {"type":
+        # "exit"} control message; bounded wait).  Before, every worker left on the first shutdown message and an arena's owner
+        # could be gone while a peer still held its IPC handles ("Producer process has been terminated before all shared CUDA
+        # tensors released" in every GPU engine test's log).
+        try:
+            tasks.exports.flush()
+        except Exception:                               # noqa: BLE001 -- a dead device: nothing to post
+            pass
+        if peers is not None:
+            try:
+                peers.close()
+            except Exception:                           # noqa: BLE001
+                pass
+            result_q.put(("__worker_event__", (worker_id, "peers_released", {})))
+            import time as _t
+
+            t_end = _t.time() + 15.0
+            while _t.time() < t_end:
+                try:
+                    if control_q.get(timeout=0.2).get("type") == "exit":
+                        break
+                except queue.Empty:
+                    pass
         result_q.put(("__worker_event__", (worker_id, "worker_exit", {})))
 
 
@@ -227,6 +300,12 @@ class ProcessTaskQueue:
 
     def put_nowait(self, task: Task):
         self._router.register(task)
+        if isinstance(task.state, RemoteStateRef) and task.state.arena.is_dead(task.state.worker_id):
+            # the row's worker ended after the hit was handed out: the state no longer exists, and the request carries only the
+            # tokens BEHIND the cached prefix -- it cannot be prefilled again here.  Completed as aborted; the client retries
+            # (its next cache lookup misses: RemoteArena.ref returns None for a dead worker's rows).
+            self._router.finish_aborted(task)
+            return
         wire = task_to_wire(task)
         if isinstance(task.state, RemoteStateRef):
             self._router.pin(task.task_id, task.state)   # released on "__installed__" (or when the task ends)
@@ -242,6 +321,18 @@ class ProcessTaskQueue:
     def get_nowait(self):                               # (used when the last worker died: drain what nobody will pull)
         return self._q.get_nowait()
 
+    def drain_affinity(self, worker_id: str) -> List[str]:
+        """Task ids of the hits still queued for `worker_id` (its process has ended: nobody may open its rows any more)."""
+        q_, out = self._affinity.get(worker_id), []
+        while q_ is not None:
+            try:
+                out.append(q_.get_nowait()["task_id"])
+            except queue.Empty:
+                break
+            except Exception:                           # noqa: BLE001 -- a queue whose peer died mid-write
+                break
+        return out
+
 
 class ResultRouter(threading.Thread):
     """Moves worker messages from the shared result queue to the asyncio-side channels of their requests."""
@@ -255,6 +346,8 @@ class ResultRouter(threading.Thread):
         self.remote_arena = remote_arena
         self._pinned: Dict[str, RemoteStateRef] = {}    # task id -> the arena row its request starts from, until installed
         self.installs = {"local": 0, "peer": 0}         # arena rows installed by their own worker / by another one (IPC)
+        self.peers_released = set()                     # workers that have dropped their views of the other workers' arenas
+        self.peers_released_cv = threading.Condition()
 
     def pin(self, task_id: str, ref: RemoteStateRef) -> None:
         with self._lock:
@@ -269,6 +362,10 @@ class ResultRouter(threading.Thread):
     def register(self, task: Task) -> None:
         with self._lock:
             self._tasks[task.task_id] = task
+
+    def task(self, task_id: str) -> Optional[Task]:
+        with self._lock:
+            return self._tasks.get(task_id)
 
     def tasks_of(self, worker_id: str) -> List[Task]:
         with self._lock:
@@ -294,8 +391,16 @@ class ResultRouter(threading.Thread):
             tid, msg = item
             if tid == "__worker_event__":
                 wid, kind, payload = msg
+                if kind == "peers_released":
+                    with self.peers_released_cv:
+                        self.peers_released.add(wid)
+                        self.peers_released_cv.notify_all()
+                    continue
                 if kind in ("worker_exit", "worker_error"):
                     self._on_exit(wid, kind)
+                    with self.peers_released_cv:        # (a worker that is gone holds no handles either)
+                        self.peers_released.add(wid)
+                        self.peers_released_cv.notify_all()
                 if kind != "worker_exit":
                     self._events.put_nowait(msg)
                 continue
@@ -318,7 +423,10 @@ class ResultRouter(threading.Thread):
                 continue
             if kind == "cache_prefill" and is_wire_row(payload.get("state")) and self.remote_arena is not None:
                 wid, row = payload["state"][WIRE_KEY]
-                payload = {"state": self.remote_arena.incoming(wid, row), "prefilled_tokens": payload["prefilled_tokens"]}
+                ref = self.remote_arena.incoming(wid, row)
+                if ref is None:                         # its worker has ended since: there is no state to cache
+                    continue
+                payload = {"state": ref, "prefilled_tokens": payload["prefilled_tokens"]}
             if kind == "task_completed":
                 task.request_status = RequestStatus(payload["request_status"])
                 task.generated_tokens, task.decoded_texts = payload["generated_tokens"], payload["decoded_texts"]

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("CHIRRUP_AMD_LIB") or os.path.join(_HERE, "libchirrup_
 _lib = None
 _lock = threading.Lock()      # worker threads may race to the first load
 
-ABI_VERSION = 3               # CHIRRUP_ABI_VERSION of include/chirrup_amd.h this module's SIGNATURES were written against
+ABI_VERSION = 4               # CHIRRUP_ABI_VERSION of include/chirrup_amd.h this module's SIGNATURES were written against
 
 E_NAMES = {-1: "CHIRRUP_E_SHAPE", -2: "CHIRRUP_E_NULL", -3: "CHIRRUP_E_ALIGN", -4: "CHIRRUP_E_UNSUPPORTED"}
 
@@ -55,7 +55,7 @@ SIGNATURES = {
     "rwkv7_tmix_wkv7_fused_mm8": (_i, [_i, _i, _i, _i] + [_vp] * 14 + [ctypes.c_float, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "rwkv7_lora_act": (_i, [_i, _i, _i64, _vp, _vp]),
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
-    "rwkv7_commit_sampled": (_i, [_i, _i] + [_vp] * 7 + [_i64, _vp]),
+    "rwkv7_commit_sampled": (_i, [_i, _i] + [_vp] * 7 + [_i64, _vp, _vp, _vp]),
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "rwkv7_embed_rows": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _vp]),
     "rwkv7_advance_elapsed": (_i, [_i, _i, _vp, _vp, _vp]),
@@ -70,8 +70,9 @@ SIGNATURES = {
     "rwkv7_tmix_sync_words": (_i, []),
     "rwkv7_tmix_status_word": (_i, []),
     "rwkv7_tmix_gemms_workspace_bytes": (_i64, [_i, _i, _i, _vp, _i, _vp, _i]),
-    "rwkv7_tmix_gemms_mm8": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "rwkv7_tmix_gemms_mm8": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "rwkv7_tmix_gemms": (_i, [_i, _i, _i, _i64, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    "chirrup_device_cu_count": (_i, []),
     "skinny_gemm_clock_probe": (_i, [_vp, _i]),
     "skinny_gemm_warm_probe": (_i, [_i, _vp]),
     "chirrup_clock_probe": (_i, [_i, _vp, _vp]),

@@ -120,13 +120,41 @@ def _sync_arena(device, will_zero: bool = False):
         return b, False
     L = _lib.load()
     n_pair = (L.skinny_gemm_pair_counters() + 63) // 64 * 64
-    n = n_pair + L.rwkv7_tmix_sync_words() + 2
+    # the counters a decode graph zeroes at the head of every replay: everything in FRONT of the time-mix launches' status word
+    # (the last sync word; the launches of this package OR into the per-device word of device_status() instead, which nothing
+    # ever zeroes -- round-3 advisor finding: the word used to sit inside the range every replay zeroed)
+    n = n_pair + L.rwkv7_tmix_status_word()
     lazy = will_zero and device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-    b = torch.empty(n, dtype=torch.int32, device=device) if lazy else torch.zeros(n, dtype=torch.int32, device=device)
+    b = torch.empty(n + 2, dtype=torch.int32, device=device) if lazy else torch.zeros(n + 2, dtype=torch.int32, device=device)
+    b = b[:n]
     _sync_backing[key] = b
     _pair_counters[key] = b[:L.skinny_gemm_pair_counters()]
     _chain_sync[key] = b[n_pair:]
     return b, not lazy
+
+
+_device_status = {}
+CHAIN_SPIN_LIMIT = 0       # polls (~0.25 us each) a bounded in-launch wait of the time-mix launch may take; 0: the library's ~0.1 s (tests: 1)
+
+
+def device_status(device) -> torch.Tensor:
+    """The STICKY status word of a device's time-mix launches (int32 [1]; include/chirrup_amd.h: rwkv7_tmix_gemms `status`): every
+    launch of this process on that device ORs into it when a bounded in-launch wait gave up, nothing zeroes it but
+    clear_chain_status().  Created outside any capture (a zero fill captured into a decode graph would erase it on every replay):
+    RWKV_x070 creates it when it is built."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _device_status.get(idx)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.ChirrupAmdError("device_status: first use inside a stream capture (call ops.device_status(device) before capturing)")
+        t = _device_status[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return t
+
+
+def clear_chain_status() -> None:
+    for t in _device_status.values():
+        t.zero_()
 
 
 def reset_launch_sync(device=None) -> None:
@@ -509,10 +537,12 @@ def copy_slot_rows(src, dst, slot_idx) -> None:
     _lib.check(rc, "rwkv7_copy_slot_rows")
 
 
-def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence) -> None:
+def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, status_out=None) -> None:
     """ONE launch for what sampling `ids` (int32 [n]) for the slots `slot_idx` (int32 [n] or None) changes on the device
     (chirrup/worker.py:527-535): last_ids[slot] = id, occurrence[slot, id] += penalty_weight[id], alpha_presence[slot, id] =
-    presence[slot, 0].  Tables fp32 [n_slots, V] contiguous, penalty_weight fp32 [V], presence fp32 [n_slots, 1] or [n_slots]."""
+    presence[slot, 0].  Tables fp32 [n_slots, V] contiguous, penalty_weight fp32 [V], presence fp32 [n_slots, 1] or [n_slots].
+    status_out (int32 [1], e.g. the element behind the ids of an [n + 1] buffer): receives the device's sticky time-mix launch
+    status (device_status) in the same launch, so that it reaches the host with the ids."""
     n = ids.numel()
     if n == 0:
         return
@@ -528,8 +558,13 @@ def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_pr
         _chk(t, name, torch.float32, shape)
     if not presence.is_cuda or presence.dtype != torch.float32 or presence.dim() not in (1, 2) or presence.shape[0] != n_slots:
         raise _lib.ChirrupAmdError("presence: expected GPU fp32 [n_slots, 1] or [n_slots]")
+    st_src = st_dst = None
+    if status_out is not None:
+        if not status_out.is_cuda or status_out.dtype != torch.int32 or status_out.numel() != 1:
+            raise _lib.ChirrupAmdError("status_out: expected a GPU int32 element")
+        st_src, st_dst = _device_status.get(status_out.device.index), status_out
     rc = _lib.load().rwkv7_commit_sampled(n, V, _ptr(ids), _ptr(slot_idx), _ptr(last_ids), _ptr(occurrence), _ptr(penalty_weight),
-                                          _ptr(alpha_presence), _ptr(presence), presence.stride(0), _stream())
+                                          _ptr(alpha_presence), _ptr(presence), presence.stride(0), _ptr(st_src), _ptr(st_dst), _stream())
     _lib.check(rc, "rwkv7_commit_sampled")
 
 
@@ -744,9 +779,10 @@ def reset_chain_sync(device=None) -> None:
 
 
 def chain_status() -> int:
-    """Non-zero when a bounded wait of any time-mix launch of this process gave up (its LoRA outputs were undefined)."""
-    i = _lib.load().rwkv7_tmix_status_word()
-    return int(sum(int(t[i]) for t in _chain_sync.values()))
+    """Non-zero when a bounded wait of any time-mix launch of this process gave up (its LoRA outputs were undefined).  Sticky
+    (device_status); a blocking read -- the serving loop gets the same word behind every step's sampled ids instead
+    (commit_sampled(status_out=...))."""
+    return int(sum(int(t[0]) for t in _device_status.values()))
 
 
 class _Mm8Problem(ctypes.Structure):
@@ -814,7 +850,8 @@ def tmix_gemms(main, lora, up_weight: "TiledWeightBatch", hid: torch.Tensor, row
     base = (ws.data_ptr() + 255) // 256 * 256
     fn, arr = (L.rwkv7_tmix_gemms_mm8, qarr) if mm8 else (L.rwkv7_tmix_gemms, marr)
     rc = fn(M, K, x0.stride(0), ldw if ldw is not None else K, len(main), ctypes.addressof(arr), len(lora),
-            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, int(row_halves), base, sync.data_ptr(), spin_limit, _stream())
+            ctypes.addressof(larr), hid.stride(1), up_n, up_k, up_ldy, int(row_halves), base, sync.data_ptr(),
+            device_status(x0.device).data_ptr(), spin_limit or CHAIN_SPIN_LIMIT, _stream())
     if rc != 0:
         try:
             sync.zero_()

@@ -72,6 +72,7 @@ class RemoteArena:
         self._send_free = send_free
         self._pins: Dict[RowId, int] = {}
         self._doomed = set()
+        self._dead = set()                    # workers that have ended: their arenas (and every row address into them) are gone
         self._lock = threading.Lock()
         self.freed: List[RowId] = []          # (for tests / telemetry)
 
@@ -83,10 +84,23 @@ class RemoteArena:
     def free_rows(self) -> int:               # allocation happens in the workers; the cache only needs "not exhausted here"
         return self.capacity
 
-    def incoming(self, worker_id: str, row: int) -> RemoteStateRef:
+    def worker_dead(self, worker_id: str) -> None:
+        """The worker process has ended (round-3 advisor finding: its rows stayed live in the engine; a hit on one was queued
+        for a dead process, and a stealer then opened the IPC handle of freed memory).  From here on ``ref`` on one of its
+        rows returns None -- SimpleStateCache drops the entry and the request prefills again -- and nothing is sent to it."""
+        with self._lock:
+            self._dead.add(worker_id)
+
+    def is_dead(self, worker_id: str) -> bool:
+        with self._lock:
+            return worker_id in self._dead
+
+    def incoming(self, worker_id: str, row: int) -> Optional[RemoteStateRef]:
         """A row a worker has just exported into (nobody owns it yet: it goes back unless a cache adopts it)."""
         rid = (worker_id, int(row))
         with self._lock:
+            if worker_id in self._dead:
+                return None
             self._pins[rid] = self._pins.get(rid, 0) + 1
             self._doomed.add(rid)
         return RemoteStateRef(self, rid)
@@ -97,8 +111,10 @@ class RemoteArena:
         ref.release()
         return ref.row
 
-    def ref(self, row: RowId) -> RemoteStateRef:
+    def ref(self, row: RowId) -> Optional[RemoteStateRef]:
         with self._lock:
+            if row[0] in self._dead:
+                return None                   # the memory is gone with its process
             self._pins[row] = self._pins.get(row, 0) + 1
         return RemoteStateRef(self, row)
 
@@ -123,7 +139,8 @@ class RemoteArena:
 
     def _free(self, row: RowId) -> None:
         self.freed.append(row)
-        self._send_free(row[0], row[1])
+        if not self.is_dead(row[0]):
+            self._send_free(row[0], row[1])
 
 
 class PeerArenas:
@@ -136,6 +153,7 @@ class PeerArenas:
         self.worker_id, self._inbox, self._outboxes = worker_id, inbox, outboxes
         self.local = None
         self._peers: Dict[str, Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._gone = set()                       # peers that have ended (engine: {"type": "peer_dead"})
 
     def publish(self, arena) -> None:
         self.local = arena
@@ -154,12 +172,33 @@ class PeerArenas:
                 wid, shift, wkv, elapsed = self._inbox.get_nowait()
             except _q.Empty:
                 return
+            except Exception:          # noqa: BLE001 -- a publication whose sender has ended since cannot be opened (its handle / its
+                continue               # shared-memory descriptor died with it): skip it, installs from that worker fail one by one
             self._peers[wid] = (shift, wkv, elapsed)
 
-    def tensors_of(self, worker_id: str, wait_s: float = 30.0):
+    def close(self) -> None:
+        """Drop every view of the other workers' arenas (their IPC handles) -- BEFORE the owning processes end: a producer that
+        exits while a consumer still holds its shared tensors prints "Producer process has been terminated before all shared
+        CUDA tensors released" (torch CudaIPCTypes.cpp) and leaves the release to process teardown order."""
+        self._drain()
+        self._peers.clear()
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            torch.cuda.ipc_collect()
+
+    def forget(self, worker_id: str) -> None:
+        """A peer has ended: its handles are stale, installs from it fail from here on."""
+        self._peers.pop(worker_id, None)
+        self._gone.add(worker_id)
+
+    def tensors_of(self, worker_id: str, wait_s: float = 1.0):
+        """(An arena is published before any address of one of its rows can exist, so the publication is already in the inbox
+        when a hit arrives: the wait only covers the queue's feeder thread.  It used to be 30 s -- inside the serving loop.)"""
         if worker_id == self.worker_id:
             a = self.local
             return a.shift, a.wkv, a.elapsed
+        if worker_id in self._gone:
+            raise RuntimeError(f"{self.worker_id}: worker {worker_id} has ended, its arena is gone")
         if worker_id not in self._peers:
             import time
 

@@ -219,6 +219,11 @@ class _LazyWeights(dict):
 _TORCH_CARRY = bool(os.environ.get("CHIRRUP_TORCH_CARRY"))
 
 
+def lib_cu_count() -> int:
+    from . import lib as _l
+    return int(_l.load().chirrup_device_cu_count())
+
+
 class RWKV_x070:
     """See module docstring.  ``wkv_impl`` is a test hook (signature of ops.forward_seq); the
     default is the HIP kernel and nothing else is ever selected automatically."""
@@ -274,6 +279,11 @@ class RWKV_x070:
         self.lora_up_row_halves = True                      # ... two row halves per tile: 256 workgroups and a deeper operand ring
         self.group_tmix_gemms = True                     # R/K/V + LoRA down-projections (+ activations) as ONE grouped launch, no side stream
         self.chain_tmix_gemms = True                     # ... and the LoRA up-projections in that SAME launch, on the CUs R/K/V leaves idle
+        if self.fused:
+            ops.device_status(self.device)               # the sticky launch-status word must exist before any decode graph is captured
+            # the chain lives on the CUs the R/K/V tiles leave idle and its workgroups wait for each other: a CU-partitioned
+            # device (CPX: 32 CUs) has neither the idle CUs nor the residency guarantee -- two launches there
+            self.chain_tmix_gemms = lib_cu_count() >= 192
         # ... from this many rows on.  A/B on one box each (profiles/r03_ab_chain_by_width.txt): from C = 2560 up the single launch wins
         # at every batch size (2.9B bsz 32 2.86 -> 2.78 ms, bsz 128 4.45 -> 4.20; 7.2B bsz 1 3.46 -> 3.43, bsz 32 3.95 -> 3.90, bsz 128
         # 5.66 -> 5.55, bsz 200 7.10 -> 6.81; 13.3B bsz 64 8.44 -> 8.28); narrower models stream their R/K/V tiles in less time than

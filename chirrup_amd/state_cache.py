@@ -43,6 +43,7 @@ class ArenaRef:
         """One strided device-to-device copy per state tensor: arena row -> slot `slot` of the worker's tables
         [L,2,n,C], [L,n,H,64,64], [n] (works across devices: a peer copy over xGMI)."""
         a = self.arena
+        a.wait_ready(self.row)               # the export into the row may still be queued on ANOTHER worker's stream
         pool[0][:, :, slot, :].copy_(a.shift[self.row], non_blocking=True)
         pool[1][:, slot].copy_(a.wkv[self.row], non_blocking=True)
         pool[2][slot: slot + 1].copy_(a.elapsed[self.row: self.row + 1], non_blocking=True)
@@ -79,6 +80,10 @@ class HbmStateArena:
         self.wkv = torch.empty((capacity, n_layer) + wkv_shape, dtype=wkv_dtype or dtype, device=device)  # state[1] rows
         self.elapsed = torch.zeros((capacity,), dtype=torch.int32, device=device)                       # state[2]
         self._free = list(range(capacity - 1, -1, -1))
+        # row -> event recorded behind the copies that filled it (device arenas): a reader on another stream -- another worker
+        # thread's install, this worker's peers in process mode (via export_event) -- must not read the row before it (round-3
+        # advisor finding: exports are non-blocking copies on the exporting worker's stream, behind its in-flight forward)
+        self._ready: Dict[int, "torch.cuda.Event"] = {}
         self._pins = [0] * capacity
         self._doomed = set()          # rows released by their owner while pinned: freed by the last unpin
         self._lock = threading.Lock()  # the cache runs on the engine's thread, installs on the worker's
@@ -111,7 +116,28 @@ class HbmStateArena:
         self.shift[row].copy_(s0[:, :, 0, :], non_blocking=True)
         self.wkv[row].copy_(s1[:, 0], non_blocking=True)
         self.elapsed[row: row + 1].copy_(s2.reshape(1), non_blocking=True)
+        self._mark_filled(row)
         return row
+
+    def _mark_filled(self, row: int) -> None:
+        if self.shift.is_cuda:
+            with torch.cuda.device(self.shift.device):
+                ev = torch.cuda.Event()
+                ev.record()                    # on the filling thread's current stream: the one the copies were enqueued on
+            self._ready[row] = ev
+
+    def export_event(self, row: int):
+        """The event behind the copies that filled `row` (None on a host arena, or when it has been waited out)."""
+        return self._ready.get(row)
+
+    def wait_ready(self, row: int) -> None:
+        """Order the CURRENT stream behind the copies that filled `row` (device-side wait; nothing on a host arena)."""
+        ev = self._ready.get(row)
+        if ev is not None:
+            if ev.query():
+                self._ready.pop(row, None)     # complete: nothing left to order against
+            else:
+                torch.cuda.current_stream().wait_event(ev)
 
     def export_slot(self, pool: Sequence[torch.Tensor], slot: int) -> "ArenaRef":
         """Copy slot `slot` of a worker's state tables straight into a free row (one strided copy per tensor) and return a
@@ -123,6 +149,7 @@ class HbmStateArena:
         self.shift[row].copy_(pool[0][:, :, slot, :], non_blocking=True)
         self.wkv[row].copy_(pool[1][:, slot], non_blocking=True)
         self.elapsed[row: row + 1].copy_(pool[2][slot: slot + 1], non_blocking=True)
+        self._mark_filled(row)
         with self._lock:
             self._pins[row] += 1
             self._doomed.add(row)           # nobody owns it yet: the row goes back when this handle is released ...
@@ -150,6 +177,7 @@ class HbmStateArena:
 
     def get(self, row: int) -> List[torch.Tensor]:
         """A device copy of row ``row`` in the layout the reference exports ([L,2,1,C], [L,1,H,64,64], [1])."""
+        self.wait_ready(row)
         return [self.shift[row].unsqueeze(2).clone(), self.wkv[row].unsqueeze(1).clone(), self.elapsed[row: row + 1].clone()]
 
     def release(self, row: int) -> None:
@@ -249,6 +277,9 @@ class SimpleStateCache:
         if key in self._lru:
             self._lru.move_to_end(key)
             state = self._materialise(self._lru[key])
+            if state is None:                      # the row's worker process has ended (RemoteArena.ref): the prefix is gone --
+                self.remove(list(key))             # forget it and look again (a shorter prefix may live elsewhere)
+                return self.check(tokens, return_trie_node)
         if return_trie_node:
             return tokens[hit:], state, hit, node
         return tokens[hit:], state, hit
@@ -326,7 +357,11 @@ class SimpleStateCache:
             await cond.wait()
         if wanted in self._lru:
             self._lru.move_to_end(wanted)
-            return list(tokens[len(wanted):]), self._materialise(self._lru[wanted]), len(wanted)
+            got = self._materialise(self._lru[wanted])
+            if got is not None:
+                return list(tokens[len(wanted):]), got, len(wanted)
+            self.remove(list(wanted))              # (its worker died in between)
+            return self.check(tokens)
         return rest, state, hit
 
     async def awake_hang_up_prefills(self, node) -> bool:

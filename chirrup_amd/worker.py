@@ -164,7 +164,7 @@ class Worker:
         self.last_ids = torch.zeros((n,), dtype=torch.int32, device=dev)
         self.penalty_weight = torch.ones((V,), **f32)           # occurrence increment per token id (worker.py:531)
         self.penalty_weight[[t for t in self.no_penalty_token_ids if t < V]] = 0.0
-        self._ids_host = ([torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self._ids_host = ([torch.zeros((n + 1,), dtype=torch.int32).pin_memory() for _ in range(2)]     # (+ 1: the launch-status word)
                           if dev.type == "cuda" else None)
         self._launches = 0
         if self.state_arena is None and self.state_arena_rows > 0:
@@ -193,6 +193,8 @@ class Worker:
                 return True
             if ev.get("type") == "arena_free" and self.state_arena is not None:
                 self.state_arena.release(int(ev["row"]))       # the engine's cache dropped the prefix: the row may be reused
+            if ev.get("type") == "peer_dead" and self.peer_arenas is not None:
+                self.peer_arenas.forget(ev["worker"])          # another worker process has ended: its arena is gone
 
     @staticmethod
     def _is_task_aborted(td) -> bool:
@@ -264,12 +266,13 @@ class Worker:
             return
         td["next_input_token"] = tok
 
-    def _commit_sampled(self, ids: torch.Tensor, didx: torch.Tensor):
+    def _commit_sampled(self, ids: torch.Tensor, didx: torch.Tensor, status_out=None):
         """Device-side consequences of sampling `ids` for the slots `didx`: the next decode input and the
-        repetition-penalty state (worker.py:527-535: occurrence += 1 except for the no-penalty ids, presence)."""
+        repetition-penalty state (worker.py:527-535: occurrence += 1 except for the no-penalty ids, presence).
+        status_out: the element behind the ids that receives the device's sticky launch-status word in the same launch."""
         if self._commit_kernel is not None:                # one launch instead of ~12 eager ones behind every decode step
             self._commit_kernel(ids, didx, self.last_ids, self.occurrence, self.penalty_weight, self.alpha_presence_vector,
-                                self.presence_penalty_tensor)
+                                self.presence_penalty_tensor, status_out=status_out)
             return
         dl, il = didx.long(), ids.long()
         self.last_ids.index_copy_(0, dl, ids)
@@ -283,7 +286,14 @@ class Worker:
             return
         if rec["event"] is not None:
             rec["event"].synchronize()
-        host_ids = rec["ids"][: len(rec["rows"])].tolist()        # ONE device->host copy for the whole batch
+        n_rows = len(rec["rows"])
+        host_ids = rec["ids"][: n_rows + (1 if rec.get("status") else 0)].tolist()        # ONE device->host copy for the whole batch
+        if rec.get("status") and host_ids[n_rows] != 0:
+            # the time-mix launch's bounded in-launch waits (include/chirrup_amd.h: rwkv7_tmix_gemms): a wait that gave up left the LoRA
+            # outputs of a step at or before this one undefined -- never seen on a GPU this process has to itself.  The sticky status
+            # word arrives behind every step's ids, so the step that gave up is fatal BEFORE any of its tokens is sent to a client
+            # (round 3 looked at a word every replay had zeroed, every 256 iterations).
+            raise RuntimeError(f"a time-mix launch gave up waiting for its own workgroups (status word {host_ids[n_rows]}): results are undefined")
         done = []
         for j, (slot, task) in enumerate(rec["rows"]):
             td = self.state_slot[slot]
@@ -329,7 +339,19 @@ class Worker:
             wid, row = task.state["__remote_row__"]
             if self.peer_arenas is None:
                 raise RuntimeError("a remote arena row arrived at a worker without peer arenas")
-            self.peer_arenas.install(wid, int(row), self.batch_state, slot)
+            try:
+                self.peer_arenas.install(wid, int(row), self.batch_state, slot)
+            except Exception as exc:              # noqa: BLE001 -- the owner of the row has ended (its IPC handle cannot be opened,
+                # or was never published): that is the end of THIS request -- it holds only the tokens behind the lost prefix --
+                # not of this worker and the requests it serves (round-3 advisor finding: the failure used to be fatal for the
+                # stealer, one dead worker cascading through the survivors)
+                import sys
+
+                print(f"{self.worker_id}: prefix state ({wid}, {row}) is unreachable ({type(exc).__name__}: {exc}); request aborted", file=sys.stderr)
+                self.task_queue.installed(task.task_id, wid != self.worker_id)
+                task.request_status = RequestStatus.FINISHED_ABORTED
+                task.output_queue.put_nowait(("task_completed", task))
+                return
             peer = wid != self.worker_id
             if peer and s1.device.type == "cuda":
                 ev = torch.cuda.Event()
@@ -422,8 +444,15 @@ class Worker:
                 logits[j, tok_id] -= 1e10
         didx = idx[:nd]
         # penalties for every decode row + arg-max, one kernel; occurrence is decayed in place
-        ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
-                                    self.frequency_penalty_tensor.view(-1), didx)
+        status_out = None
+        if self._commit_kernel is not None and self.device.type == "cuda":
+            buf = torch.empty((nd + 1,), dtype=torch.int32, device=self.device)     # the ids, and the launch-status word behind them
+            ids, status_out = buf[:nd], buf[nd:]
+            self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
+                                  self.frequency_penalty_tensor.view(-1), didx, out=ids)
+        else:
+            ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
+                                        self.frequency_penalty_tensor.view(-1), didx)
         if sampled:
             if self._sample_topp is not None and logits.shape[1] <= 65536:
                 # sort-free top-p / top-k / temperature kernel, one workgroup per sampled row
@@ -434,15 +463,19 @@ class Worker:
                 srows = didx.long()[lrows]
                 ids[lrows] = sample_logits_rwkv_pip_compatible(logits[lrows], self.temperature_tensor[srows],
                                                                self.top_p_tensor[srows], self.top_k_tensor[srows]).to(torch.int32)
-        self._commit_sampled(ids, didx)
+        self._commit_sampled(ids, didx, status_out)
         event = None
         if self._ids_host is not None:
             host = self._ids_host[self._launches & 1]
-            host[:nd].copy_(ids, non_blocking=True)
+            if status_out is not None:
+                host[:nd + 1].copy_(buf, non_blocking=True)
+            else:
+                host[:nd].copy_(ids, non_blocking=True)
             event = torch.cuda.Event()
             event.record()
             ids = host
-        return {"rows": [(s, self.state_slot[s]["task"]) for s in decode_slots], "ids": ids, "event": event, "raw": raw}
+        return {"rows": [(s, self.state_slot[s]["task"]) for s in decode_slots], "ids": ids, "event": event, "raw": raw,
+                "status": status_out is not None and self._ids_host is not None}
 
     def _graph_for(self, n: int):
         """Smallest captured bucket >= n (buckets: powers of two up to the slot count)."""
@@ -481,6 +514,9 @@ class Worker:
         (2) enqueue this iteration's forward(s), (3) handle sampled ids -- those of the PREVIOUS iteration's
         forward when running ahead, else this one's."""
         t0 = time.perf_counter()
+        poll_exports = getattr(self.task_queue, "poll_exports", None)
+        if poll_exports is not None:                   # process mode: row addresses whose export copies have completed may leave now
+            poll_exports()
         if self._pending_installs:                     # copies out of another worker's arena: report those that have completed
             still = []
             for ev, task_id in self._pending_installs:
@@ -529,13 +565,6 @@ class Worker:
             rec, self._inflight = self._inflight, rec
         self._handle_results(rec)
         self.iterations += 1
-        if self.use_graph and (self.iterations & 255) == 0:
-            # the time-mix launch's bounded in-launch waits (include/chirrup_amd.h: rwkv7_tmix_gemms): a wait that gave up left that
-            # step's LoRA outputs undefined -- never seen on a GPU this process has to itself; fatal rather than silently wrong
-            from . import ops
-
-            if ops.chain_status():
-                raise RuntimeError("a time-mix launch gave up waiting for its own workgroups (status word set): results are undefined")
         self.loop_time_recorder.append(time.perf_counter() - t0)
         if (self.iterations & 63) == 1 or self._max_mem_gb is None:      # (memory_stats() walks a dictionary of ~150 counters: 0.12 ms per call)
             self._max_mem_gb = (torch.cuda.max_memory_allocated() / 1024 ** 3) if torch.cuda.is_available() else 0.0

@@ -34,8 +34,10 @@ extern "C" {
  *   2  round 2: skinny_gemm_f16 / _f16_group / _f16_partial gained row_halves (and tile_counters) ahead of `stream`,
  *      skinny_gemm_f16_grouped gained w_tiled, skinny_gemm_group_workspace_bytes gained K, skinny_gemm_select removed
  *   3  round 3: chirrup_mm8_fuse gained out_planes (the struct grew); new entry points only otherwise (rwkv7_tmix_gemms,
- *      rwkv7_tmix_gemms_mm8, rwkv7_tmix_wkv7_fused_mm8, skinny_untile_weight, the clock probes) */
-#define CHIRRUP_ABI_VERSION 3
+ *      rwkv7_tmix_gemms_mm8, rwkv7_tmix_wkv7_fused_mm8, skinny_untile_weight, the clock probes)
+ *   4  round 4: rwkv7_tmix_gemms / _mm8 gained `status` (a sticky status word of the caller's) ahead of spin_limit and the status
+ *      word moved to the END of the sync words; rwkv7_commit_sampled gained status_src / status_dst ahead of `stream` */
+#define CHIRRUP_ABI_VERSION 4
 int chirrup_abi_version(void);
 const char *chirrup_target_arch(void);
 
@@ -324,8 +326,13 @@ int skinny_gemm_f16(int M, int N, int K, const void *X, int ldx, const void *W, 
  * ZERO before the first launch (every completed launch leaves it zero; the workgroups hand tiles to each other through it with
  * write-through stores, one agent-scope atomic per workgroup and ONE agent-scope acquire per consumer: cdna_hip_programming.md
  * Guideline 16).  Every wait is bounded (spin_limit polls of ~0.25 us, 0 = default ~0.1 s): if one gives up -- another tenant
- * held most of the chip that long -- sync[rwkv7_tmix_status_word()] is set non-zero and this launch's LoRA outputs are undefined.
- * One launch at a time per (workspace, sync).
+ * held most of the chip that long -- the STATUS word is OR-ed non-zero and this launch's LoRA outputs are undefined.  status: an
+ * int32 of the caller's (one per device is enough: launches only ever OR into it, nobody but its owner clears it), or NULL =
+ * sync[rwkv7_tmix_status_word()], the LAST sync word; words [0, rwkv7_tmix_status_word()) may be zeroed between launches at
+ * any time (a captured decode graph zeroes them at the head of every replay) -- the status word must not be, or a step that
+ * gave up is erased by the next one (ABI 4; rwkv7_commit_sampled hands the word to the host behind every step's sampled ids).
+ * One launch at a time per (workspace, sync).  All chain workgroups must be resident at once (they wait for each other):
+ * CHIRRUP_E_UNSUPPORTED on a device with fewer compute units than the chain has workgroups (chirrup_device_cu_count()).
  */
 typedef struct {
     const void *x;      /* [M][ldx] binary16 */
@@ -354,12 +361,14 @@ int64_t rwkv7_tmix_gemms_workspace_bytes(int M, int K, int n_main, const chirrup
                                          const chirrup_lora_problem *lora, int row_halves);
 int rwkv7_tmix_gemms(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_gemm_problem *main_problems, int n_lora,
                      const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves, void *workspace,
-                     void *sync, int spin_limit, void *stream);
+                     void *sync, void *status, int spin_limit, void *stream);
+/* Compute units of the current device (what the time-mix launch sizes its chain by). */
+int chirrup_device_cu_count(void);
 /* ... with uint8 main problems (R/K/V as mm8 weights; the rank-1 corrections run in each tile's epilogue); the LoRA problems,
  * workspace (size it with the binary16 call's function, passing n and w_tiled of the uint8 problems) and sync as above. */
 int rwkv7_tmix_gemms_mm8(int M, int K, int ldx, int64_t ldw, int n_main, const chirrup_mm8_problem *main_problems, int n_lora,
                          const chirrup_lora_problem *lora, int ld_hid, int up_n, int up_kimg, int up_ldy, int row_halves,
-                         void *workspace, void *sync, int spin_limit, void *stream);
+                         void *workspace, void *sync, void *status, int spin_limit, void *stream);
 /* Weights in the ring kernel's tile-image layout (w_tiled = 1 above and in chirrup_gemm_problem): W [N][K] binary16,
  * N % 128 == 0, K % 64 == 0, re-laid so that each (128 rows x 64 k) tile is 16 KiB of consecutive bytes in the order the
  * kernel keeps it in LDS.  A 1-KiB LDS-DMA wave-instruction then reads 1 KiB of consecutive memory instead of eight
@@ -401,10 +410,13 @@ int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const f
 /* The device-side consequences of sampling ids[row] for slot slot_idx[row] (row when slot_idx is NULL), row < n
  * (reference: chirrup/worker.py:527-535): last_ids[slot] = id; occurrence[slot][id] += penalty_weight[id];
  * alpha_presence[slot][id] = presence[slot * presence_stride].  occurrence / alpha_presence fp32 [n_slots][V],
- * penalty_weight fp32 [V], last_ids int32 [n_slots].  An id outside [0, V) only updates last_ids. */
+ * penalty_weight fp32 [V], last_ids int32 [n_slots].  An id outside [0, V) only updates last_ids.
+ * status_dst (may be NULL): *status_dst = status_src ? *status_src : 0 -- the sticky launch-status word of the time-mix launches
+ * (rwkv7_tmix_gemms) placed behind the ids (status_dst = ids + n of a buffer of n + 1), so that the ONE device-to-host copy of a
+ * step's ids also tells the host whether that step's launches gave up a bounded wait. */
 int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
                          const float *penalty_weight, float *alpha_presence, const float *presence, int64_t presence_stride,
-                         void *stream);
+                         const int32_t *status_src, int32_t *status_dst, void *stream);
 
 /* The two ends of a decode step around the layers (Albatross/rwkv7.py:503-517 `_pre`: the embedding gather; :561-563 `_post`:
  * state[2] += T), each one launch.  rwkv7_embed_rows: x[b][t] = emb[token], token = tokens[b*T + t], or -- when that is negative and

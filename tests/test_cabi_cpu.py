@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/chirrup_amd.h but not exported"
         assert name in lib.SIGNATURES, f"{name} has no ctypes signature in chirrup_amd/lib.py"
     header = open(os.path.join(ROOT, "include", "chirrup_amd.h")).read()
-    assert int(re.search(r"#define\s+CHIRRUP_ABI_VERSION\s+(\d+)", header).group(1)) == lib.ABI_VERSION == L.chirrup_abi_version() == 3
+    assert int(re.search(r"#define\s+CHIRRUP_ABI_VERSION\s+(\d+)", header).group(1)) == lib.ABI_VERSION == L.chirrup_abi_version() == 4
     assert L.chirrup_target_arch() == b"gfx950"
 
 

@@ -295,3 +295,100 @@ def test_process_mode_prefix_states_travel_as_arena_row_addresses():
     assert with_affinity["peer"] == 0 or with_affinity["local"] > 0      # the owner pulls its own hits first
     without = asyncio.run(run(False))
     assert without["peer"] > 0                                            # the other process installed some through the owner's arena
+
+
+def test_a_dead_workers_arena_rows_are_dropped_and_never_opened():
+    """Round-3 advisor finding (engine_core.py:128): when a worker process ends, the rows of ITS arena must die with it in the
+    engine's books.  Two worker processes with arenas; the owner of a cached prefix is killed.  Afterwards: a cache lookup of
+    that prefix misses (the entry is dropped, the request prefills again on the survivor and streams the right tokens); a hit
+    that was handed out BEFORE the death and is submitted after it completes as aborted at once (it holds only the tokens
+    behind the lost prefix) instead of waiting in a dead process's queue; the survivor keeps serving."""
+    import time
+
+    from chirrup_amd.remote_arena import RemoteStateRef
+    from chirrup_amd.state_cache import SimpleStateCache
+
+    async def main():
+        eng = AsyncEngineCore(worker_factory=_process_factory, tokenizer=_Tok(), worker_mode="process", state_arena_rows=4)
+        cfg = ModelLoadConfig(model_path="fake", vocab_path="fake", vocab_size=V, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=2, model_config=cfg, batch_size=4), 120)
+        cache = SimpleStateCache(max_size=4, arena=eng.state_arena)
+        kw = dict(temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[])
+        p = list(range(1, 25))
+        c = eng.completion("", prefill_tokens=list(p), max_tokens=4, cache_prefill=True, cache_prefill_padding=3, **kw)
+        evs = [ev async for ev in c]
+        hit = [e[1] for e in evs if e[0] == "cache_prefill"][0]
+        assert isinstance(hit["state"], RemoteStateRef)
+        owner = hit["state"].worker_id
+        cache.cache(hit["prefilled_tokens"], hit["state"])
+        rest, early_ref, n_hit = cache.check(list(p))              # a hit handed out while the owner is alive ...
+        assert isinstance(early_ref, RemoteStateRef) and n_hit == len(p) - 3
+        victim = [w for w in eng.workers if w.worker_id == owner][0]
+        victim.process.kill()
+        t_end = time.time() + 30
+        while not eng.state_arena.is_dead(owner) and time.time() < t_end:
+            await asyncio.sleep(0.05)
+        assert eng.state_arena.is_dead(owner)
+        c = eng.completion("", prefill_tokens=rest, state=early_ref, max_tokens=4, **kw)   # ... submitted after its death
+        await asyncio.wait_for(c.get_full_completion(), 30)
+        assert str(c.task.request_status) == "FINISHED_ABORTED"
+        rest2, state2, n_hit2 = cache.check(list(p))               # the lookup now misses and forgets the prefix
+        assert state2 is None and n_hit2 == 0 and rest2 == p and len(cache) == 0
+        c = eng.completion("", prefill_tokens=list(p), max_tokens=5, **kw)
+        assert await asyncio.wait_for(c.get_full_completion(), 60) == "".join(f"<{t}>" for t in expected_stream(p, 5))
+        eng.shutdown()
+
+    asyncio.run(main())
+
+
+def test_pending_exports_post_a_row_address_only_behind_its_copies():
+    """Round-3 advisor finding (engine_process.py:64): the ("cache_prefill", row address) message of an export into a device
+    arena must not leave the worker before the export's copies have completed.  Fake events stand in for the HIP events."""
+    from chirrup_amd.engine_process import PendingExports, ResultSink
+
+    class Ev:
+        def __init__(self):
+            self.done, self.synced = False, False
+
+        def query(self):
+            return self.done
+
+        def synchronize(self):
+            self.done = self.synced = True
+
+    class Arena:
+        def __init__(self):
+            self.ev = Ev()
+
+        def export_event(self, row):
+            return self.ev
+
+        def adopt(self, ref):
+            return ref.row
+
+    class Ref:
+        def __init__(self, arena, row):
+            self.arena, self.row = arena, row
+
+    q = queue.Queue()
+    pend, arena = PendingExports(q), Arena()
+    sink = ResultSink(q, "t1", worker_id="worker_0", arena=arena, exports=pend)
+    sink.put_nowait(("cache_prefill", {"state": Ref(arena, 3), "prefilled_tokens": (1, 2)}))
+    assert q.empty()                                   # copies in flight: nothing has left
+    pend.poll()
+    assert q.empty()
+    sink.put_nowait(("token_generated", (5, "x")))     # other messages are not held back
+    assert q.get_nowait() == ("t1", ("token_generated", (5, "x")))
+    arena.ev.done = True
+    pend.poll()
+    tid, (kind, payload) = q.get_nowait()
+    assert (tid, kind) == ("t1", "cache_prefill") and payload["state"] == {"__remote_row__": ("worker_0", 3)}
+    # a request that completes while its export is in flight: the address goes out FIRST (waited for), then the completion
+    arena.ev = Ev()
+    sink.put_nowait(("cache_prefill", {"state": Ref(arena, 1), "prefilled_tokens": (1,)}))
+    assert q.empty()
+    from chirrup_amd.core_structure import Task
+    t = Task(output_queue=None, task_event_queue=None, prompt_str="", prefill_tokens=[], state=None)
+    sink.put_nowait(("task_completed", t))
+    assert arena.ev.synced
+    assert q.get_nowait()[1][0] == "cache_prefill" and q.get_nowait()[1][0] == "task_completed"

@@ -57,3 +57,39 @@ def test_two_rank_replicas_gloo():
     assert res[0][2] >= 5 * 0.04 * 0.9                       # ... and it is the slower rank's time
     assert all(r[3] for r in res)                            # every request's stream is the single-replica stream
     assert abs(res[0][4] - 2 * 200 * 5 / res[0][2]) < 1e-6   # whole-job value counts both ranks' units
+
+
+def _bench(args, extra_env=None, timeout=180):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, [json.loads(ln) for ln in lines], r.stderr
+
+
+def test_bench_gpus_2_without_a_launcher_makes_two_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must BE the launcher (round 3 ran
+    one rank and printed n_gpus 1).  Through that exact entry, gloo, the launch protocol only (--rehearse-launch: no model, no
+    GPU call): two ranks rendezvous on 127.0.0.1, the timed region is the slower rank's, rank 0 prints the ONE JSON line.
+    Reference layout: chirrup/engine_core.py:135-153 (worker k <-> gpu k)."""
+    rc, lines, err = _bench(["--gpus", "2", "--steps", "4", "--rehearse-launch"], {"CHIRRUP_BENCH_BACKEND": "gloo"})
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    j = lines[0]
+    assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["backend"] == "gloo" and len(j["per_rank_ms_per_step"]) == 2
+    assert j["per_rank_ms_per_step"][1] > j["per_rank_ms_per_step"][0] * 1.5            # rank 1 sleeps twice as long ...
+    assert j["ms_per_step"] >= max(j["per_rank_ms_per_step"]) * 0.999                   # ... and the line carries the slower rank's time
+
+
+def test_bench_fan_out_fails_when_a_rank_fails():
+    rc, lines, err = _bench(["--gpus", "2", "--steps", "2", "--rehearse-launch"],
+                            {"CHIRRUP_BENCH_BACKEND": "gloo", "CHIRRUP_BENCH_REHEARSE_FAIL_RANK": "1"}, timeout=120)
+    assert rc != 0 and not lines and "ranks failed" in err
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    rc, lines, err = _bench(["--gpus", "2", "--rehearse-launch"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and not lines and "must agree" in err

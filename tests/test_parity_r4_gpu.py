@@ -1,0 +1,140 @@
+"""Round-4 GPU tests: regression tests of the round-3 advisor findings on the device side (the sticky launch-status word and
+its hand-off to the host with every step's ids) and the parity cases added this round."""
+import queue
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Tok:
+    def decode(self, ids, utf8_errors="strict"):
+        return "".join(chr(65 + i % 26) for i in ids)
+
+
+class _Sink:
+    def __init__(self):
+        self.items = []
+
+    def put_nowait(self, x):
+        self.items.append(x)
+
+
+def _chained_model(C=1024, L=2, V=1024, seed=5):
+    """A small stack whose time-mix projections run as the ONE-launch chain at every batch size (chain_min_rows = 1)."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from chirrup_amd.synth import make_state_dict
+
+    zd = make_state_dict(L, C, V, seed=seed, varied_norms=True)
+    m = RWKV_x070(types.SimpleNamespace(vocab_size=V, head_size=64, MODEL_NAME="unused"), state_dict=zd, device="cuda:0", skinny_min_embd=0)
+    m.chain_min_rows = 1
+    assert m.chain_tmix_gemms and m._layers[0].lora2_t is not None
+    return m
+
+
+def test_status_word_of_a_time_mix_launch_survives_graph_replays():
+    """Round-3 advisor finding (chirrup_amd/ops.py:480): the status word of the time-mix launch sat inside the range that the
+    first launch of every decode-graph replay zeroes, so a step whose bounded in-launch waits gave up (LoRA outputs undefined)
+    was erased by the next step.  Now the word is per device, outside every reset range, and launches only OR into it.  A wait
+    budget of ONE poll (ops.CHAIN_SPIN_LIMIT = 1, baked into the captured launches) makes the waits give up."""
+    from chirrup_amd import ops
+
+    m = _chained_model()
+    B = 32
+    ops.clear_chain_status()
+    try:
+        ops.CHAIN_SPIN_LIMIT = 1
+        st = m.generate_zero_state(B)
+        g = m.capture_decode_graph(st)                       # (its warm-up launches already give up)
+        ops.CHAIN_SPIN_LIMIT = 0
+        torch.cuda.synchronize()
+        assert ops.chain_status() != 0
+        ops.clear_chain_status()
+        tok = torch.randint(1, 1000, (B, 1), device="cuda")
+        g.step(tok)
+        torch.cuda.synchronize()
+        first = ops.chain_status()
+        assert first != 0                                    # the replayed launches gave up as well ...
+        # ... and a healthy launch stream afterwards does not erase it: replays of a graph captured with the default budget zero
+        # the hand-off words at their head, the status word stays
+        g2 = m.capture_decode_graph(m.generate_zero_state(B))
+        for _ in range(3):
+            g2.step(tok)
+        torch.cuda.synchronize()
+        assert ops.chain_status() == first
+        # every hand-off word in front of the status word is back at zero (the healthy launches left them so)
+        assert all(int(t.abs().sum()) == 0 for t in ops._chain_sync.values())
+    finally:
+        ops.CHAIN_SPIN_LIMIT = 0
+        ops.clear_chain_status()
+    # with the word clear and the default budget, the healthy graph sets nothing
+    g2.step(tok)
+    torch.cuda.synchronize()
+    assert ops.chain_status() == 0
+
+
+def test_commit_sampled_hands_the_status_word_over_behind_the_ids():
+    from chirrup_amd import ops
+
+    dev = torch.device("cuda", 0)
+    n, V = 7, 512
+    st = ops.device_status(dev)
+    ops.clear_chain_status()
+    buf = torch.full((n + 1,), -5, dtype=torch.int32, device=dev)
+    buf[:n] = torch.arange(n, dtype=torch.int32, device=dev) * 3
+    occ, alpha = torch.zeros((n, V), device=dev), torch.zeros((n, V), device=dev)
+    args = (None, torch.zeros(n, dtype=torch.int32, device=dev), occ, torch.ones(V, device=dev), alpha, torch.zeros((n, 1), device=dev))
+    ops.commit_sampled(buf[:n], *args, status_out=buf[n:])
+    assert buf.tolist() == [0, 3, 6, 9, 12, 15, 18, 0]
+    st.fill_(3)
+    ops.commit_sampled(buf[:n], *args, status_out=buf[n:])
+    assert buf.tolist()[-1] == 3 and int(st[0]) == 3          # copied, not consumed
+    ops.clear_chain_status()
+    ops.commit_sampled(buf[:n], *args)                        # without status_out nothing behind the ids is touched
+    assert buf.tolist()[-1] == 3
+
+
+def test_worker_dies_on_the_step_whose_time_mix_launch_gave_up():
+    """... and the serving loop sees it with the ids of the failing step itself: Worker.step() raises before any token of that
+    step is sent (round 3 polled a word that every replay had zeroed, every 256 iterations: up to 255 steps of undefined
+    outputs would have streamed to clients)."""
+    from chirrup_amd import ops
+    from chirrup_amd.core_structure import ModelLoadConfig, Task
+    from chirrup_amd.worker import Worker
+
+    m = _chained_model()
+    V = 1024
+    cfg = ModelLoadConfig(model_path="unused", vocab_path="unused", vocab_size=V, head_size=64)
+
+    made = []
+
+    def serve(n_steps):
+        tq, mq = queue.Queue(), queue.Queue()
+        w = Worker("w0", [0], cfg, tq, mq, None, batch_size=9, model=m, tokenizer=_Tok())
+        w._init_worker()
+        rng = np.random.default_rng(3)
+        tasks = [Task(output_queue=_Sink(), task_event_queue=queue.Queue(), prompt_str="", prefill_tokens=rng.integers(1, V, 3).tolist(), state=None,
+                      temperature=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=64) for _ in range(8)]
+        made.append(tasks)
+        for t in tasks:
+            tq.put(t)
+        for _ in range(n_steps):
+            w.step()
+        return w, tasks
+
+    ops.clear_chain_status()
+    w, tasks = serve(12)                                      # healthy: tokens flow, nothing raised
+    assert all(any(x[0] == "token_generated" for x in t.output_queue.items) for t in tasks)
+    try:
+        ops.CHAIN_SPIN_LIMIT = 1                              # graphs captured from here on carry a one-poll wait budget
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            serve(12)
+        # the graph's warm-up launches had already given up: the FIRST decode step's ids arrive with the word set, no token left the worker
+        assert not any(x[0] == "token_generated" for t in made[-1] for x in t.output_queue.items)
+    finally:
+        ops.CHAIN_SPIN_LIMIT = 0
+        torch.cuda.synchronize()
+        ops.clear_chain_status()
