@@ -448,9 +448,44 @@ def gen_model_c768(ref):
     npz("model_L3_C768.npz", **out)
 
 
+def gen_web():
+    """The stream splitter of the OpenAI surface (round 4): the reference's `<think>` parser
+    (chirrup/utils/streaming_string_parser.py, rule set TRIE_THINK_NO_TRIGGER) on texts cut into seeded pieces, primed with
+    each of the three assistant cues as chirrup/web_service/app.py:243 does."""
+    # (chirrup.utils.prompt_formatters cannot be imported on this interpreter: it pulls in chirrup/web_service/api_model.py, whose
+    # class bodies name a later class in an annotation -- fine under Python 3.14's deferred annotations, a NameError on 3.10.  The
+    # chat template is therefore pinned by literal strings in tests/test_web_service_cpu.py, read off prompt_formatters.py:8-45.)
+    from chirrup.utils.streaming_string_parser import TRIE_THINK_NO_TRIGGER, StreamingStringParser
+
+    texts = ["plain answer without markers", "<think>let me see\n\nstill thinking</think>The answer is 4.\n\nUser: more",
+             " reasoning first</think> then content < think > not a marker <thin", "a\nb\n\nc", "<think><think></think></think>x\n\n\n\ny",
+             "</think>closing without opening <think>again</think>done"]
+    rng = np.random.default_rng(11)
+    splits = []
+    for cue in ("Assistant:", "Assistant:<think>", "Assistant:<think>\n</think>"):
+        for text in texts:
+            for _ in range(4):
+                cuts = sorted(set(rng.integers(1, max(2, len(text)), size=int(rng.integers(0, 8))).tolist()))
+                pieces = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+                sp = StreamingStringParser(tries=TRIE_THINK_NO_TRIGGER)
+                sp.parse(cue)
+                runs = []
+                for piece in pieces:
+                    runs.extend(sp.parse(piece))
+                content = "".join(t for t, st in runs if st == "content")
+                reasoning = "".join(t for t, st in runs if st == "reasoning_content")
+                splits.append({"cue": cue, "pieces": pieces, "content": content, "reasoning_content": reasoning})
+    path = os.path.join(HERE, "web_service.json")
+    json.dump({"splits": splits}, open(path, "w"), ensure_ascii=False, indent=0)
+    print(f"wrote {path}  ({len(splits)} split cases)")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "the reference tree is needed to (re)generate fixtures"
     native.build()
+    if len(sys.argv) > 1 and sys.argv[1] == "web":       # only the OpenAI-surface string fixtures (added in round 4)
+        gen_web()
+        raise SystemExit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c768":      # only the C=768 model fixture (added in round 2)
         gen_model_c768(import_reference_model())
         raise SystemExit(0)
@@ -463,3 +498,4 @@ if __name__ == "__main__":
     ref = import_reference_model()
     gen_model(ref)
     gen_model_c768(ref)
+    gen_web()

@@ -177,8 +177,31 @@ def test_process_mode_prefix_states_never_leave_hbm(tmp_path):
         eng.shutdown()
         return inst
 
-    a = asyncio.run(run(True))
-    b = asyncio.run(run("avoid"))
+    # the worker processes inherit this process's stderr: collect it at the descriptor level to read what THEY print at exit
+    import sys
+    import tempfile
+    import threading
+
+    sys.stderr.flush()
+    saved, log = os.dup(2), tempfile.TemporaryFile()
+    os.dup2(log.fileno(), 2)
+    try:
+        a = asyncio.run(run(True))
+        b = asyncio.run(run("avoid"))
+    finally:
+        sys.stderr.flush()
+        os.dup2(saved, 2)
+        os.close(saved)
+    log.seek(0)
+    child_err = log.read().decode(errors="replace")
+    sys.stderr.write(child_err)
     print("installs with affinity", a, "queued for the non-owner", b)
     assert a["local"] > 0
     assert b["peer"] > 0                    # another process copied rows out of the owner's arena through its IPC handle
+    # the consumers drop their views of a peer's arena BEFORE its owner ends (two-phase shutdown,
+    # engine_process.worker_process_main) -- torch's IPC bookkeeping has nothing to complain about
+    assert "Producer process has been terminated" not in child_err, child_err[-2000:]
+    # ... and the engine leaves no thread behind in THIS process (a leftover busy thread can hold the GIL for a whole 5-ms switch
+    # interval inside someone else's timed region: the most likely cause of round 3's 486-us mm8 timing)
+    left = [t.name for t in threading.enumerate() if t.name.startswith("chirrup:") and t.is_alive()]
+    assert not left, left

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import bits
+from util import bits, check_bar, parity_stats, record_parity
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -28,6 +28,12 @@ def _model(fused):
     return d, RWKV_x070(args, state_dict=zd, device="cuda:0", fused=fused)
 
 
+# Bars = measured error (profiles/r04_parity_errors.txt, MI355X) x <= 1.25, per tensor (shift state, wkv state, logits), relative to
+# max(1, max|want|).  T = 1: north_star's 1e-3 holds outright; T = 5 adds up five tokens of summation-order noise.
+C128_BARS = {"b1t1": (1.5e-3, 1e-3, 2e-3), "b3t1": (1.5e-3, 1e-3, 2e-3), "b3t5": (1.5e-3, 2e-3, 2e-3), "b1t5": (1.5e-3, 2e-3, 2e-3)}
+C768_BARS = {"b2t1": (3e-3, 1.5e-3, 2e-3), "b2t5": (3e-3, 2.5e-3, 2e-3)}
+
+
 @pytest.fixture(scope="module", params=[False, True], ids=["torch_ops", "fused"])
 def setup(request):
     return _model(request.param)
@@ -43,9 +49,21 @@ def test_forward_vs_reference_fixture(setup, tag):
     st = [torch.from_numpy(d[f"{tag}:{n}_in"].copy()).cuda() for n in ("s0", "s1", "s2")]
     lg = m.forward_seq_batch_seperate(d[f"{tag}:tokens"].tolist(), st)
     assert np.array_equal(st[2].cpu().numpy(), d[f"{tag}:s2_out"])
-    assert rel_linf(st[0].cpu().numpy(), d[f"{tag}:s0_out"]) <= 1.5e-3
-    assert rel_linf(st[1].cpu().numpy(), d[f"{tag}:s1_out"]) <= (1e-3 if tag.endswith("t1") else 2e-3)
-    assert rel_linf(lg.cpu().numpy(), d[f"{tag}:logits"]) <= 2e-3
+    case = f"C128 reference fixture {tag} ({'fused' if m.fused else 'torch_ops'})"
+    bars = C128_BARS[tag]
+    for name, got, want, bar in (("shift state", st[0], d[f"{tag}:s0_out"], bars[0]), ("wkv state", st[1], d[f"{tag}:s1_out"], bars[1]),
+                                 ("logits", lg, d[f"{tag}:logits"], bars[2])):
+        check_bar(case, name, parity_stats(got.cpu().numpy(), want), bar)
+    if tag.endswith("t1"):
+        # north_star in its own terms: ONE decode step, ABSOLUTE state error <= 1e-3 -- assertable wherever the state's magnitude is
+        # below 1 (binary16 resolves 1e-3 only there: at |S| in [4, 8) one ulp is 3.9e-3)
+        for name, got, want in (("wkv state", st[1], d[f"{tag}:s1_out"]), ("shift state", st[0], d[f"{tag}:s0_out"])):
+            w = want.astype(F32)
+            small = np.abs(w) < 1.0
+            err = float(np.abs(got.cpu().numpy().astype(F32) - w)[small].max())
+            record_parity(case, tensor=name + ", elements with |S| < 1", bar=1e-3, bar_on="abs_linf", abs_linf=err,
+                          fraction_of_elements=float(small.mean()), max_abs_want=float(np.abs(w).max()))
+            assert err <= 1e-3, (case, name, err)
 
 
 def test_greedy_token_ids_bit_exact(setup):
@@ -53,14 +71,18 @@ def test_greedy_token_ids_bit_exact(setup):
     st = m.generate_zero_state(2)
     lg = m.forward_seq_batch_seperate(d["greedy:prompt"].tolist(), st)
     ids = []
+    worst = 0.0
     for s in range(d["greedy:ids"].shape[1]):
-        assert rel_linf(lg.cpu().numpy(), d["greedy:step_logits"][:, s]) <= 3e-3
+        worst = max(worst, rel_linf(lg.cpu().numpy(), d["greedy:step_logits"][:, s]))
         nxt = lg.float().argmax(dim=-1)
         ids.append(nxt.cpu().numpy())
         lg = m.forward_seq_batch_seperate([[int(t)] for t in nxt.tolist()], st)
     assert np.array_equal(np.stack(ids, 1), d["greedy:ids"])
     assert np.array_equal(st[2].cpu().numpy(), d["greedy:s2_final"])
-    assert rel_linf(st[1].cpu().numpy(), d["greedy:s1_final"]) <= 3e-3
+    case = f"C128 reference fixture, 21-token greedy run ({'fused' if m.fused else 'torch_ops'})"
+    record_parity(case, tensor="logits, worst step", bar=3e-3, bar_on="rel_linf", rel_linf=worst)
+    assert worst <= 3e-3
+    check_bar(case, "wkv state after the run", parity_stats(st[1].cpu().numpy(), d["greedy:s1_final"]), 3e-3)
 
 
 def test_graph_replay_equals_eager(setup):
@@ -99,9 +121,19 @@ def test_larger_config_vs_reference_fixture(fused):
         st = [torch.from_numpy(t).cuda() for t in st_np]
         lg = m.forward_seq_batch_seperate(toks, st)
         assert np.array_equal(st[2].cpu().numpy(), d[f"{tag}:s2_out"])
-        assert rel_linf(st[0].cpu().numpy(), d[f"{tag}:s0_out"]) <= 3e-3
-        assert rel_linf(st[1].cpu().numpy(), d[f"{tag}:s1_out"]) <= (1.5e-3 if tag.endswith("t1") else 2.5e-3)
-        assert rel_linf(lg.cpu().numpy(), d[f"{tag}:logits"]) <= 2e-3
+        case = f"C768 reference fixture {tag} ({'fused' if fused else 'torch_ops'})"
+        bars = C768_BARS[tag]
+        for name, got, want, bar in (("shift state", st[0], d[f"{tag}:s0_out"], bars[0]), ("wkv state", st[1], d[f"{tag}:s1_out"], bars[1]),
+                                     ("logits", lg, d[f"{tag}:logits"], bars[2])):
+            check_bar(case, name, parity_stats(got.cpu().numpy(), want), bar)
+        if tag.endswith("t1"):                      # north_star's own terms (see the C = 128 test): |S| < 1 -> absolute 1e-3
+            for name, got, want in (("wkv state", st[1], d[f"{tag}:s1_out"]), ("shift state", st[0], d[f"{tag}:s0_out"])):
+                w = want.astype(F32)
+                small = np.abs(w) < 1.0
+                err = float(np.abs(got.cpu().numpy().astype(F32) - w)[small].max())
+                record_parity(case, tensor=name + ", elements with |S| < 1", bar=1e-3, bar_on="abs_linf", abs_linf=err,
+                              fraction_of_elements=float(small.mean()), max_abs_want=float(np.abs(w).max()))
+                assert err <= 1e-3, (case, name, err)
     st = m.generate_zero_state(B)
     lg = m.forward_seq_batch_seperate(d["greedy:prompt"].tolist(), st)
     ids = []
@@ -111,8 +143,9 @@ def test_larger_config_vs_reference_fixture(fused):
         lg = m.forward_seq_batch_seperate([[int(t)] for t in nxt.tolist()], st)
     assert np.array_equal(np.stack(ids, 1), d["greedy:ids"])
     assert np.array_equal(st[2].cpu().numpy(), d["greedy:s2_final"])
-    assert rel_linf(st[1].cpu().numpy(), d["greedy:s1_final"]) <= 3e-3
-    assert rel_linf(lg.cpu().numpy(), d["greedy:final_logits"]) <= 3e-3
+    case = f"C768 reference fixture, 6 + 12-token greedy run ({'fused' if fused else 'torch_ops'})"
+    check_bar(case, "wkv state after the run", parity_stats(st[1].cpu().numpy(), d["greedy:s1_final"]), 3e-3)
+    check_bar(case, "final logits", parity_stats(lg.cpu().numpy(), d["greedy:final_logits"]), 3e-3)
 
 
 def test_larger_config_vs_numpy_oracle(oracle):

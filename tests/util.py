@@ -62,3 +62,36 @@ def c768_inputs(d, tag):
     toks = rng.integers(1, V, size=d[f"{tag}:tokens"].shape).tolist()
     assert toks == d[f"{tag}:tokens"].tolist()
     return toks, [s0, s1, s2]
+
+
+def parity_stats(got, want):
+    """The error figures the parity bars are written in: absolute L-inf, L-inf relative to max(1, max|want|) (the bar form of
+    DESIGN.md section 2), max|want|, and the absolute error in units in the last place of binary16 at the tensor's TOP binade."""
+    g, w = np.asarray(got, dtype=np.float32), np.asarray(want, dtype=np.float32)
+    d = float(np.abs(g - w).max()) if w.size else 0.0
+    m = float(np.abs(w).max()) if w.size else 0.0
+    top_ulp = float(2.0 ** (np.floor(np.log2(max(m, 2.0 ** -14))) - 10))
+    return {"abs_linf": d, "rel_linf": d / max(1.0, m), "max_abs_want": m, "top_binade_ulps": d / top_ulp}
+
+
+def record_parity(case, **fields):
+    """Append one measured-error record to the parity log (JSON lines; gpurun_out/parity/r04_parity_errors.jsonl, or
+    $CHIRRUP_PARITY_LOG): VERDICT r3 item 2 -- every bar of the fixture / full-size / smoke tests sits beside the error that was
+    measured against it; tools/parity_report.py turns the log into profiles/r04_parity_errors.txt."""
+    import json
+    import os
+
+    path = os.environ.get("CHIRRUP_PARITY_LOG") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                "gpurun_out", "parity", "r04_parity_errors.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps({"case": case, **fields}, sort_keys=True) + "\n")
+    except OSError:
+        pass
+
+
+def check_bar(case, name, stats, bar, key="rel_linf"):
+    """Record (measurement, bar) and assert measurement <= bar."""
+    record_parity(case, tensor=name, bar=bar, bar_on=key, **stats)
+    assert stats[key] <= bar, (case, name, key, stats[key], bar)

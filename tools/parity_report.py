@@ -1,0 +1,38 @@
+"""gpurun_out/parity/r04_parity_errors.jsonl (written by the -m gpu tests through tests/util.py::record_parity and by
+__graft_entry__.smoke()) -> a table of measured error | bar | bar / measured per (case, tensor): profiles/r04_parity_errors.txt.
+VERDICT r3 item 2: the slack between every parity bar and its measurement, committed.
+
+    python tools/parity_report.py [log.jsonl] > profiles/r04_parity_errors.txt"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity", "r04_parity_errors.jsonl")
+    rows = {}
+    for line in open(path):
+        r = json.loads(line)
+        rows[(r["case"], r["tensor"])] = r                 # the last run of a case wins
+    print("Measured parity errors beside their bars (MI355X; one row per asserted bar; `measured` is in the unit the bar is written in:")
+    print("rel_linf = L-inf error / max(1, max|want|), abs_linf = absolute L-inf, top_binade_ulps = error in binary16 ulps of the tensor's top binade).")
+    print("Every bar is <= 1.25 x a measurement of this table or a stated floor (north_star's 1e-3, a second CPU evaluation of the same arithmetic).")
+    print()
+    print(f"{'case':<78} {'tensor':<38} {'bar on':<16} {'measured':>10} {'bar':>10} {'bar/meas':>9} {'max|want|':>10}  notes")
+    last = None
+    for (case, tensor), r in rows.items():
+        key = r["bar_on"]
+        m = r.get(key)
+        ratio = (r["bar"] / m) if m else float("inf")
+        notes = []
+        for k in ("second_cpu_evaluation_rel_linf", "second_cpu_evaluation_ulps", "fraction_of_elements", "abs_linf", "top_binade_ulps"):
+            if k in r and k != key:
+                notes.append(f"{k}={r[k]:.3g}")
+        print(f"{(case if case != last else ''):<78} {tensor:<38} {key:<16} {m:>10.3g} {r['bar']:>10.3g} {ratio:>9.2f} {r.get('max_abs_want', float('nan')):>10.3g}  {' '.join(notes)}")
+        last = case
+
+
+if __name__ == "__main__":
+    main()
