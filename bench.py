@@ -57,6 +57,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mm8-leg", action="store_true", help="skip the second (uint8 FFN) model of the mm8 object")
     p.add_argument("--no-engine-leg", action="store_true", help="skip the Worker-loop measurement of the engine object")
+    p.add_argument("--no-serving-leg", action="store_true", help="skip the serving run on SURVEY 8d's inputs (64-token prompts, 256 new tokens per request)")
     p.add_argument("--no-penalties", action="store_true", help="plain arg-max instead of the worker's penalty tables + commit (round 1's step)")
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
     p.add_argument("--sync-ids", action="store_true", help="blocking D2H of the ids every step (the worker's run_ahead=False)")
@@ -607,6 +608,92 @@ def engine_iterations(model, B, a, dev, rank, steps):
     return dt
 
 
+def serving_run(model, B, dev, rank, prompt_len=64, new_tokens=256):
+    """The serving loop on SURVEY.md section 8d's inputs: B requests arrive at once, each a `prompt_len`-token prompt (ids from
+    randint(1, 65536), seed 1234 + rank) followed by `new_tokens` greedy tokens -- admission, CHUNKED PREFILL under the reference's
+    cadence (at most B/8 sequences per chunk, one chunk every decode_prefill_ratio = 5 decode iterations: chirrup/worker.py:143,
+    :179, :854-856), decode with a batch that grows as prompts finish, completion.  Timed from the first step to the last
+    completion (barrier + sync on both sides, max over ranks).  What the bare step and the steady-state `engine` leg cannot show:
+    the prefill chunks between the decode steps."""
+    import queue
+
+    from chirrup_amd.core_structure import ModelLoadConfig, Task
+    from chirrup_amd.dist_util import gather_floats
+    from chirrup_amd.worker import Worker
+
+    class Tok:
+        def decode(self, ids, utf8_errors="strict"):
+            return "x"
+
+    class Sink:
+        def __init__(self):
+            self.first = self.last = None
+            self.n = 0
+            self.done = False
+
+        def put_nowait(self, x):
+            if x[0] == "token_generated":
+                self.last = time.perf_counter()
+                self.first = self.first if self.first is not None else self.last
+                self.n += 1
+            elif x[0] == "task_completed":
+                self.done = True
+
+    cfg = ModelLoadConfig(model_path="synthetic", vocab_path="none", vocab_size=65536, head_size=64)
+    tq, mq = queue.Queue(), queue.Queue()
+    w = Worker(f"worker_{rank}", [dev.index], cfg, tq, mq, None, batch_size=B + 1, model=model, tokenizer=Tok())
+    w._init_worker()
+    # warm-up outside the timed region: the graph buckets and library GEMM plans this run will use (one short request per bucket size)
+    g = torch.Generator().manual_seed(99 + rank)
+    warm = [Sink() for _ in range(B)]
+    for s_ in warm:
+        tq.put(Task(output_queue=s_, task_event_queue=queue.Queue(), prompt_str="", state=None,
+                    prefill_tokens=torch.randint(1, 65536, (prompt_len,), generator=g).tolist(), temperature=0.0, top_p=0.0,
+                    frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=3))
+    while not all(s_.done for s_ in warm):
+        w.step()
+    while w.step():
+        pass
+    torch.cuda.synchronize(dev)
+    n_seq = [0]
+    seq_fn = w._run_forward_seq
+
+    def counted(slots):
+        n_seq[0] += 1
+        return seq_fn(slots)
+
+    w._run_forward_seq = counted
+    g = torch.Generator().manual_seed(1234 + rank)
+    sinks = [Sink() for _ in range(B)]
+    for s_ in sinks:
+        tq.put(Task(output_queue=s_, task_event_queue=queue.Queue(), prompt_str="", state=None,
+                    prefill_tokens=torch.randint(1, 65536, (prompt_len,), generator=g).tolist(), temperature=0.0, top_p=0.0,
+                    frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, stop_tokens=[], max_tokens=new_tokens))
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    iters = 0
+    while not all(s_.done for s_ in sinks):
+        w.step()
+        iters += 1
+    while w.step():
+        pass
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0
+    if dist.is_initialized():
+        dist.barrier()
+    dt = max(gather_floats(local, dev))
+    assert all(s_.n == new_tokens for s_ in sinks)
+    tpot = sorted((s_.last - s_.first) / (new_tokens - 1) for s_ in sinks)
+    ttft = sorted(s_.first - t0 for s_ in sinks)
+    w.shutdown_flag = True
+    del w
+    torch.cuda.empty_cache()
+    return {"seconds": dt, "iterations": iters, "prefill_chunks": n_seq[0], "tpot_ms_median": tpot[len(tpot) // 2] * 1e3,
+            "ttft_ms_median": ttft[len(ttft) // 2] * 1e3, "ttft_ms_max": ttft[-1] * 1e3}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -703,11 +790,12 @@ def main():
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
     wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
-    engine_dt = None
+    engine_dt = serving = None
     if not a.no_engine_leg and not a.no_graph and not a.no_fused:
         del state
         engine_steps = max(a.steps, 60)              # (20 iterations are 0.14 s: box-to-box clock drift showed up as 1.00-1.035x)
         engine_dt = engine_iterations(model, B, a, dev, rank, engine_steps)
+        serving = serving_run(model, B, dev, rank) if not a.no_serving_leg else None
         state = make_state(model, B)
     gemm_t = gemm_shape_timings(model, B) if (rank == 0 and not os.environ.get("CHIRRUP_BENCH_NO_GEMM_LEG")) else {}      # (the env switch: per-kernel profiles of the step alone)
     clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
@@ -778,6 +866,17 @@ def main():
                                      "host bookkeeping + messages, run-ahead), one worker process per GPU", "ms_per_iteration": round(ems, 4),
                              "value": round(world * B * engine_steps / engine_dt, 1), "iterations": engine_steps, "unit": "tokens/s", "tps_per_request": round(1e3 / ems, 2),
                              "vs_bare_step": round(ems / ms_per_step, 4)}
+        if serving is not None:
+            n_new, n_prompt = 256, 64
+            out["serving"] = {"what": f"{B} requests per GPU arriving at once through chirrup_amd.worker.Worker: {n_prompt}-token prompts (chunked prefill under the "
+                                      f"reference's cadence: <= {max(B // 8, 1)} sequences per chunk, one chunk per 5 decode iterations) + {n_new} greedy tokens each "
+                                      "(SURVEY.md 8d's inputs); first step -> last completion",
+                              "seconds": round(serving["seconds"], 4), "generated_tokens_per_s": round(world * B * n_new / serving["seconds"], 1),
+                              "prompt_plus_generated_tokens_per_s": round(world * B * (n_new + n_prompt) / serving["seconds"], 1),
+                              "iterations": serving["iterations"], "prefill_chunks": serving["prefill_chunks"],
+                              "tpot_ms_median": round(serving["tpot_ms_median"], 3), "tps_per_request_median": round(1e3 / serving["tpot_ms_median"], 2),
+                              "ttft_ms_median": round(serving["ttft_ms_median"], 1), "ttft_ms_max": round(serving["ttft_ms_max"], 1),
+                              "decode_only_bound_s": round(n_new * ms_per_step / 1e3, 4)}
         if regions:
             out["ms_per_step_median"] = round(regions[len(regions) // 2], 4)
             out["ms_per_step_regions"] = {"n": len(regions), "min": round(regions[0], 4), "max": round(regions[-1], 4),

@@ -160,6 +160,39 @@ __global__ __launch_bounds__(256) void mm8_pack_kernel(const int N, const int M,
     }
 }
 
+// uint8 weights wT [M_out][N_in] (K-contiguous; the 8-KiB tile images of mm8_pack / skinny_tile_weight_u8, or row-major with row
+// stride w_stride)  ->  the dequantised matrix as binary16 [M_out][N_in] row-major: out[m][k] = fp16(((q + 0.5) * rx[m]) * ry[k] +
+// mx[m] + my[k]), the as-coded dequantisation (rwkv_pip_operators.cu:76-79, left to right in binary32) rounded once.  What a
+// chunked-prefill forward multiplies through the library GEMM: above 256 rows a product is MFMA-bound, the weights' bytes no longer
+// matter, and one 40-us pass that rebuilds a layer's matrix into a reused scratch costs less than re-streaming uint8 tiles
+// per 256-row block (round 3: 2500 rows took 10 x 52 us per ffn product against 290 us for the binary16 library call).
+__global__ __launch_bounds__(256) void mm8_dequant_kernel(const int M, const int N, const uint8_t *__restrict__ wT, const int64_t w_stride,
+                                                          const int tiled, const f16 *__restrict__ rx, const f16 *__restrict__ mx,
+                                                          const f16 *__restrict__ ry, const f16 *__restrict__ my, f16 *__restrict__ out) {
+    const int ng = blockIdx.x, kb = blockIdx.y, tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c = p * 256 + tid;                                   // 16-byte chunk of the (128 x 64) tile
+        const int nr = c >> 2;
+        const int lc = tiled ? ((c & 3) ^ ((nr >> 2) & 3)) : (c & 3);  // logical chunk held at position c & 3 of row nr
+        const int m = ng * 128 + nr, k0 = kb * 64 + lc * 16;
+        if (m >= M) continue;
+        const uint8_t *src = tiled ? wT + ((int64_t)ng * (N / 64) + kb) * 8192 + c * 16 : wT + (int64_t)m * w_stride + k0;
+        const uint4 q4 = *reinterpret_cast<const uint4 *>(src);
+        const uint32_t qs[4] = {q4.x, q4.y, q4.z, q4.w};
+        const float rxm = (float)rx[m], mxm = (float)mx[m];
+        f16 o[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float wq = (float)((qs[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            o[e] = (f16)((wq + 0.5f) * rxm * (float)ry[k0 + e] + mxm + (float)my[k0 + e]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + (int64_t)m * N + k0);
+        dst[0] = *reinterpret_cast<const uint4 *>(o);
+        dst[1] = *reinterpret_cast<const uint4 *>(o + 8);
+    }
+}
+
 inline bool mfma_eligible(int N, int M, const void *x, int x_stride, const void *w, int w_stride, int y_stride) {
     return N % 64 == 0 && M % 128 == 0 && (w_stride & 15) == 0 && (x_stride & 7) == 0 && (y_stride & 3) == 0 &&
            (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
@@ -180,6 +213,18 @@ extern "C" int mm8_pack(int N, int M, const void *w, int w_stride, void *packed,
     if (N / 64 > 65535) return CHIRRUP_E_SHAPE;
     hipLaunchKernelGGL(mm8_pack_kernel, dim3(M / 128, N / 64), dim3(256), 0, static_cast<hipStream_t>(stream), N, M,
                        static_cast<const uint8_t *>(w), w_stride, static_cast<uint8_t *>(packed));
+    return (int)hipGetLastError();
+}
+
+extern "C" int mm8_dequant_f16(int M_out, int N_in, const void *wT, int64_t w_stride, int w_tiled, const void *rx, const void *mx,
+                               const void *ry, const void *my, void *out, void *stream) {
+    if (M_out <= 0 || N_in <= 0 || (N_in % 64) || (w_tiled && (M_out % 128)) || (!w_tiled && (w_stride < N_in || (w_stride & 15)))) return CHIRRUP_E_SHAPE;
+    if (!wT || !rx || !mx || !ry || !my || !out) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(wT) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CHIRRUP_E_ALIGN;
+    if (N_in / 64 > 65535) return CHIRRUP_E_SHAPE;
+    hipLaunchKernelGGL(mm8_dequant_kernel, dim3((M_out + 127) / 128, N_in / 64), dim3(256), 0, static_cast<hipStream_t>(stream), M_out, N_in,
+                       static_cast<const uint8_t *>(wT), w_stride, w_tiled ? 1 : 0, static_cast<const f16 *>(rx), static_cast<const f16 *>(mx),
+                       static_cast<const f16 *>(ry), static_cast<const f16 *>(my), static_cast<f16 *>(out));
     return (int)hipGetLastError();
 }
 

@@ -1360,9 +1360,13 @@ inline bool wide_ok(int N, int ldy, const void *Y, int64_t y_bs = 0) {
 }
 
 // mm8 activation prologue: xs = fp16(x * ry), S[m] = {sum xs, sum x*my, sum x}   (benchmark.py:167-173)
+// xs_lo != NULL (mm8t_seq_exact): the product x*ry of two binary16 numbers has at most 22 significant bits, so it is EXACT in
+// binary32 and splits exactly into two binary16 numbers, hi = fp16(p) and lo = fp16(p - hi) (lo below 2^-14 loses its last bits
+// to the subnormal grid: <= 2^-25 absolute); S0 then sums hi + lo.  Two matrix-core passes (hi, lo) with binary32 accumulation
+// reproduce the as-coded expression's arithmetic -- products exact, sums in binary32 -- instead of rounding xs to binary16.
 __global__ __launch_bounds__(256) void mm8_prep_kernel(const int K, const f16 *__restrict__ x, const int ldx,
                                                        const f16 *__restrict__ ry, const f16 *__restrict__ my,
-                                                       f16 *__restrict__ xs, float *__restrict__ S) {
+                                                       f16 *__restrict__ xs, float *__restrict__ S, f16 *__restrict__ xs_lo = nullptr) {
     __shared__ float red[3][4];
     const int m = blockIdx.x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -1370,15 +1374,18 @@ __global__ __launch_bounds__(256) void mm8_prep_kernel(const int K, const f16 *_
         const f16x8 xv = *reinterpret_cast<const f16x8 *>(x + (int64_t)m * ldx + c);
         const f16x8 rv = *reinterpret_cast<const f16x8 *>(ry + c);
         const f16x8 mv = *reinterpret_cast<const f16x8 *>(my + c);
-        f16x8 o;
+        f16x8 o, lo;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            o[e] = (f16)((float)xv[e] * (float)rv[e]);
-            s0 += (float)o[e];
+            const float p = (float)xv[e] * (float)rv[e];
+            o[e] = (f16)p;
+            lo[e] = (f16)(p - (float)o[e]);
+            s0 += xs_lo ? (float)o[e] + (float)lo[e] : (float)o[e];
             s1 += (float)xv[e] * (float)mv[e];
             s2 += (float)xv[e];
         }
         *reinterpret_cast<f16x8 *>(xs + (int64_t)m * K + c) = o;
+        if (xs_lo) *reinterpret_cast<f16x8 *>(xs_lo + (int64_t)m * K + c) = lo;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -2215,6 +2222,67 @@ extern "C" int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride,
                                                 nullptr, part, bs);
         if (rc) return rc;
         rc = launch_reduce(wide_ok(M_out, y_stride, yb), 1, st, bn, M_out, s, part, nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2,
+                           yb, y_stride);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// mm8t_seq with the arithmetic of the reference's mm8_seq (kernel_mm_seq_fp16i8, rwkv_pip_operators.cu:59-83: the as-coded
+// expression, every product and sum in binary32) at matrix-core speed: x*ry is split exactly into two binary16 operands
+// (mm8_prep_kernel, xs_lo) and multiplied in two passes whose binary32 partial planes the reduce adds with the rank-1
+// corrections.  What still differs from the as-coded kernel is the ORDER of the binary32 sums (and the regrouping of
+// (q + 0.5) * rx * ry + mx + my into the split form): ~1e-6 of the row scale, against 2e-3 for the one-pass split form that
+// rounds xs to binary16 (the reference's own mm8_seq_opt does that too, rwkv_pip_wrapper.cpp:148-191).
+// workspace layout: xs_hi [B][N_in] f16 | xs_lo [B][N_in] f16 | S [B][3] f32 | partials [2 * splits][B][M_out] f32
+extern "C" int64_t mm8t_exact_workspace_bytes(int B, int N_in, int M_out, int splits) {
+    if (B <= 0 || N_in <= 0 || M_out <= 0) return 0;
+    if (B > 256) B = 256;
+    const int s = pick_splits(choose_bn(M_out), M_out, N_in, splits);
+    int64_t b = 2 * (((int64_t)B * N_in * 2 + 255) / 256 * 256);
+    b += 256 * ((B * 3 * 4 + 255) / 256);
+    b += (int64_t)2 * s * B * M_out * 4;
+    return b;
+}
+
+extern "C" int mm8t_seq_exact(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
+                              const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
+                              int splits, void *workspace, void *stream) {
+    if (w_tiled && (M_out % kTileRows)) return CHIRRUP_E_UNSUPPORTED;
+    if (B <= 0 || N_in <= 0 || M_out <= 0 || (M_out & 3) || (N_in % kKB) || x_stride < N_in || w_stride < N_in ||
+        y_stride < M_out || (x_stride & 7) || (w_stride & 15) || (y_stride & 3))
+        return CHIRRUP_E_SHAPE;
+    if (!x || !wT || !mx || !rx || !my || !ry || !y || !workspace) return CHIRRUP_E_NULL;
+    if (mis16(x) || mis16(wT) || (reinterpret_cast<uintptr_t>(workspace) & 255)) return CHIRRUP_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(mx) & 7) || (reinterpret_cast<uintptr_t>(rx) & 7) || mis16(my) || mis16(ry)) return CHIRRUP_E_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int bnc = choose_bn(M_out);
+    const int s = pick_splits(bnc, M_out, N_in, splits);
+    const int Bmax = B < 256 ? B : 256;
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const int64_t xs_bytes = ((int64_t)Bmax * N_in * 2 + 255) / 256 * 256;
+    f16 *xs_hi = reinterpret_cast<f16 *>(ws), *xs_lo = reinterpret_cast<f16 *>(ws + xs_bytes);
+    int64_t off = 2 * xs_bytes;
+    float *S = reinterpret_cast<float *>(ws + off);
+    off += 256 * ((Bmax * 3 * 4 + 255) / 256);
+    float *part = reinterpret_cast<float *>(ws + off);
+    for (int b0 = 0; b0 < B; b0 += 256) {
+        const int bn = (B - b0) < 256 ? (B - b0) : 256;
+        const f16 *xb = static_cast<const f16 *>(x) + (int64_t)b0 * x_stride;
+        f16 *yb = static_cast<f16 *>(y) + (int64_t)b0 * y_stride;
+        hipLaunchKernelGGL(mm8_prep_kernel, dim3(bn), dim3(256), 0, st, N_in, xb, x_stride, (const f16 *)ry, (const f16 *)my,
+                           xs_hi, S, xs_lo);
+        const int MT = (bn + 15) / 16;
+        const dim3 grid((M_out + bnc - 1) / bnc, s);
+        BatchStrides bs{};
+        bs.tiled = w_tiled ? 1 : 0;
+        int rc = launch_gemm<true, EPI_PARTIAL>(bnc, MT, grid, st, bn, M_out, N_in, N_in / s, xs_hi, N_in, wT, w_stride, yb, y_stride,
+                                                nullptr, part, bs);
+        if (rc) return rc;
+        rc = launch_gemm<true, EPI_PARTIAL>(bnc, MT, grid, st, bn, M_out, N_in, N_in / s, xs_lo, N_in, wT, w_stride, yb, y_stride,
+                                            nullptr, part + (int64_t)s * bn * M_out, bs);
+        if (rc) return rc;
+        rc = launch_reduce(wide_ok(M_out, y_stride, yb), 1, st, bn, M_out, 2 * s, part, nullptr, (const f16 *)rx, (const f16 *)mx, S, act ? 3 : 2,
                            yb, y_stride);
         if (rc) return rc;
     }

@@ -85,6 +85,9 @@ SIGNATURES = {
     "skinny_gemm_f16": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mm8t_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "mm8t_seq": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "mm8_dequant_f16": (_i, [_i, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mm8t_exact_workspace_bytes": (_i64, [_i, _i, _i, _i]),
+    "mm8t_seq_exact": (_i, [_i, _i, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "skinny_tile_weight_u8": (_i, [_i, _i, _vp, _i64, _vp, _vp]),
 }
 

@@ -268,18 +268,7 @@ def _mm8_packed(w: torch.Tensor, N: int, M: int) -> Optional[torch.Tensor]:
     return packed
 
 
-def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
-    """rwkv_pip::mm8_seq / mm8_seq_opt (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84, :206-211):
-    y[B,M] = x[B,N] @ dequant(w[N,M]), on the matrix cores (include/chirrup_amd.h: mm8_seq).  The weight is packed
-    once per tensor (see _mm8_packed); shapes the packed layout cannot hold, and operands that miss mm8t_seq's alignment
-    (views of the scale vectors, odd strides), run the as-coded kernel.
-
-    Arithmetic: the SPLIT form -- xs = binary16(x*ry), core = xs . (1024 + q) in binary32 on the matrix cores, then
-    y = rx*(core - 1023.5*sum xs) + sum x*my + mx*sum x.  That is the form of the reference's own half-precision
-    `mm8_seq_opt` (rwkv_pip_wrapper.cpp:148-191: preprocess / cuBLAS / postprocess, which additionally keeps `core` in
-    binary16); the reference's `mm8_seq` evaluates the as-coded expression with binary32 accumulation (rwkv_pip_operators.cu:
-    59-83), so under THAT name this op differs from the reference by the rounding of xs (<= 2e-3 of the row scale, bounded
-    against oracle_mm8_seq in tests/test_mm8_spmv_gpu.py); `mm8_seq_direct` is the bit-exact as-coded kernel."""
+def _mm8_seq_mfma(B, N, M, x, w, mx, rx, my, ry, y, exact: bool) -> None:
     L = _lib.load()
     mx, rx, my, ry = _mm8_check(B, N, M, x, w, mx, rx, my, ry, y)
     # mm8t_seq's preconditions (include/chirrup_amd.h): anything else runs the as-coded kernel instead of failing with E_ALIGN
@@ -290,11 +279,34 @@ def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
         rc = L.mm8_seq_direct(B, N, M, x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), mx.data_ptr(), rx.data_ptr(),
                               my.data_ptr(), ry.data_ptr(), y.data_ptr(), y.stride(0), _stream())
         return _lib.check(rc, "mm8_seq_direct")
-    ws = _workspace(L.mm8t_workspace_bytes(B, N, M, 0) + 256, x.device)
+    fn, nbytes = (L.mm8t_seq_exact, L.mm8t_exact_workspace_bytes(B, N, M, 0)) if exact else (L.mm8t_seq, L.mm8t_workspace_bytes(B, N, M, 0))
+    ws = _workspace(nbytes + 256, x.device)
     base = (ws.data_ptr() + 255) // 256 * 256
-    rc = L.mm8t_seq(B, N, M, x.data_ptr(), x.stride(0), packed.data_ptr(), N, 1, mx.data_ptr(), rx.data_ptr(), my.data_ptr(),
-                    ry.data_ptr(), y.data_ptr(), y.stride(0), 0, 0, base, _stream())
-    _lib.check(rc, "mm8t_seq")
+    rc = fn(B, N, M, x.data_ptr(), x.stride(0), packed.data_ptr(), N, 1, mx.data_ptr(), rx.data_ptr(), my.data_ptr(),
+            ry.data_ptr(), y.data_ptr(), y.stride(0), 0, 0, base, _stream())
+    _lib.check(rc, "mm8t_seq_exact" if exact else "mm8t_seq")
+
+
+def mm8_seq(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """rwkv_pip::mm8_seq (scripts/test_mm8/rwkv_pip_wrapper.cpp:51-84, :206): y[B,M] = x[B,N] @ dequant(w[N,M]) with the
+    arithmetic of the reference's kernel under THAT name (kernel_mm_seq_fp16i8, rwkv_pip_operators.cu:59-83: every product and
+    sum in binary32), on the matrix cores: x*ry is split exactly into two binary16 operands and multiplied in two passes
+    (include/chirrup_amd.h: mm8t_seq_exact).  What differs from the as-coded kernel is the order of the binary32 sums: the
+    binary16 results agree bit for bit on ~99 % of the elements and within one ulp on the rest (tests/test_mm8_spmv_gpu.py;
+    round 3 ran the one-pass split form under this name, 2e-3 of the row scale away).  The weight is packed once per tensor
+    (see _mm8_packed); shapes the packed layout cannot hold, and operands that miss mm8t_seq's alignment (views of the scale
+    vectors, odd strides), run the as-coded kernel `mm8_seq_direct` (bit-identical to the oracle, not MFMA)."""
+    _mm8_seq_mfma(B, N, M, x, w, mx, rx, my, ry, y, exact=True)
+
+
+def mm8_seq_opt(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
+    """rwkv_pip::mm8_seq_opt (rwkv_pip_wrapper.cpp:148-191, :208): the reference's half-precision optimised form -- preprocess
+    (xs = binary16(x*ry), row sums) / matrix product / postprocess (rank-1 corrections).  Here: xs = binary16(x*ry), core =
+    xs . (1024 + q) in binary32 on the matrix cores (the reference keeps `core` in binary16 through cuBLAS), then
+    y = rx*(core - 1023.5*sum xs) + sum x*my + mx*sum x -- ONE pass over the weights, within 2e-3 of the row scale of the as-coded
+    expression (the reference's own bar between its two forms is 1e-3, benchmark_pure_pytorch.py:92).  This is the form the
+    model's uint8 projections use (ffn_dtype / att_dtype = int8)."""
+    _mm8_seq_mfma(B, N, M, x, w, mx, rx, my, ry, y, exact=False)
 
 
 def mm8_seq_direct(B: int, N: int, M: int, x, w, mx, rx, my, ry, y) -> None:
@@ -912,6 +924,23 @@ def mm8t_linear(x, wT, mx, rx, my, ry, act: int = 0, splits: int = 0, out=None, 
     return out
 
 
+def mm8_dequant(wT, mx, rx, my, ry, tiled: bool = False, out=None) -> torch.Tensor:
+    """The dequantised matrix of an Mm8Weight as binary16 [M_out, N_in] (include/chirrup_amd.h: mm8_dequant_f16): what a forward
+    of more than 256 rows multiplies through the library GEMM (y = x @ out.T).  out: a reused scratch of M_out * N_in elements."""
+    M, N = mx.shape[0], my.shape[0]
+    if not wT.is_cuda or wT.dtype != torch.uint8 or wT.numel() != M * N or (not tiled and (wT.dim() != 2 or wT.stride(1) != 1)):
+        raise _lib.ChirrupAmdError("wT: expected GPU uint8 [M_out, N_in] (or its flat tile-image form)")
+    _chk16("mx", mx, M), _chk16("rx", rx, M), _chk16("my", my, N), _chk16("ry", ry, N)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float16, device=wT.device)
+    elif not out.is_cuda or out.dtype != torch.float16 or out.numel() < M * N or not out.is_contiguous():
+        raise _lib.ChirrupAmdError("out: expected a contiguous GPU fp16 buffer of M_out * N_in elements")
+    rc = _lib.load().mm8_dequant_f16(M, N, wT.data_ptr(), N if tiled else wT.stride(0), int(tiled), rx.data_ptr(), mx.data_ptr(), ry.data_ptr(),
+                                     my.data_ptr(), out.data_ptr(), _stream())
+    _lib.check(rc, "mm8_dequant_f16")
+    return out.view(-1)[: M * N].view(M, N)
+
+
 def mm8t_gemm_partial(xs, wT, M_out: int, splits: int, partials, tiled: bool = False, row_halves: bool = False):
     """The matrix product of mm8t_linear alone: xs [B<=256, N_in] fp16 (an mm8 prologue's output) against wT; fp32 core sums
     into `partials`, returned as the view [splits_used, B, M_out] (include/chirrup_amd.h: mm8t_gemm_partial)."""
@@ -1092,7 +1121,7 @@ def register_torch_ops() -> None:
         },
         "rwkv_pip": {
             "mm8_seq": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
-            "mm8_seq_opt": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq),
+            "mm8_seq_opt": (f"(int B, int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_seq_opt),
             "mm8_one": (f"(int N, int M, {T} x, {T} w, {T} mx, {T} rx, {T} my, {T} ry, {T}(a!) y) -> ()", mm8_one),
             "gemm_fp16_cublas": (f"({T} a, {T} b, {T}(a!) c) -> ()", gemm_fp16_cublas),
         },

@@ -270,6 +270,7 @@ class RWKV_x070:
         self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
+        self.mm8_prefill_dequant = True                  # uint8 ffn above 256 rows: dequantise into a binary16 scratch + library GEMM (False: 256-row blocks through the ring kernel)
         self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
         self.mm8_pair_key = True                         # ... and at few rows: the K split reduced inside the launch, the same epilogue (no mm8_reduce_rows launch)
         self.mm8_pair_max_rows = 16                      # A/B on one box (profiles/r03_mm8_pair_key.txt): 7.2B bsz 8 3.11 -> 3.07 ms; bsz 32 3.37 -> 3.38, 1.5B bsz 32 1.687 -> 1.70,
@@ -343,6 +344,14 @@ class RWKV_x070:
             if not self.keep_row_major:
                 self._drop_row_major()
             torch.cuda.empty_cache()
+
+    def _mm8_scratch(self, numel: int):
+        """Two binary16 scratch matrices of `numel` elements (ffn.key's and ffn.value's dequantised forms during a chunked-prefill
+        forward), one pair per model: launches on a stream run in order, so every layer reuses them."""
+        sc = getattr(self, "_mm8_scratch_buf", None)
+        if sc is None or sc[0].numel() < numel:
+            sc = self._mm8_scratch_buf = tuple(torch.empty((numel,), dtype=DTYPE, device=self.device) for _ in range(2))
+        return sc
 
     # ------------------------------------------------------------------ tile-image-only weights (keep_row_major=False)
     def _drop_row_major(self):
@@ -798,6 +807,25 @@ class RWKV_x070:
                     ops.mm8_reduce_rows(kparts, lw.f_K8.rx, lw.f_K8.mx, S_k, act=1, nxt=(lw.f_V8.ry, lw.f_V8.my, xs_v, S_v))
                 dparts, delta = ops.mm8t_gemm_partial(xs_v, lw.f_V8.qT, C, gs["ffn_value"], pbuf, tiled=lw.f8_tiled, row_halves=rh["ffn_value"]), None
                 dq = (lw.f_V8.rx, lw.f_V8.mx, S_v)
+            elif self.ffn_dtype == torch.int8 and rows > 256 and self.mm8_prefill_dequant:
+                # chunked prefill: above 256 rows a product is MFMA-bound and the ring kernel would re-stream the uint8 tiles once
+                # per 256-row block (2500 rows: 10 x 52 us per product against 290 us for a binary16 library call).  One pass
+                # rebuilds the layer's dequantised matrix as binary16 into a scratch shared by all layers (40-80 us: 67 MB in,
+                # 134 MB out), then the library GEMM of the binary16 path -- what the reference's own mm8_seq_opt does in front of
+                # cuBLAS (rwkv_pip_wrapper.cpp:163-176), with the dequantisation as coded (:76-79) instead of a cast.
+                sK, sV = self._mm8_scratch(4 * C * C)
+                wK16 = ops.mm8_dequant(*lw.f_K8, tiled=lw.f8_tiled, out=sK)          # [4C, C]
+                kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
+                kv2, xin = kf.view(rows, 4 * C), kin[0].view(rows, C)
+                if rows >= self.split_rows_min:
+                    half = (rows + 1) // 2
+                    torch.mm(xin[:half], wK16.t(), out=kv2[:half])
+                    torch.mm(xin[half:], wK16.t(), out=kv2[half:])
+                else:
+                    torch.mm(xin, wK16.t(), out=kv2)
+                ops.relu_sq_(kf)
+                wV16 = ops.mm8_dequant(*lw.f_V8, tiled=lw.f8_tiled, out=sV)          # [C, 4C]
+                delta = F.linear(kf, wV16)
             elif self.ffn_dtype == torch.int8:      # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)
                 delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)

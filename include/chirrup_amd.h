@@ -36,7 +36,8 @@ extern "C" {
  *   3  round 3: chirrup_mm8_fuse gained out_planes (the struct grew); new entry points only otherwise (rwkv7_tmix_gemms,
  *      rwkv7_tmix_gemms_mm8, rwkv7_tmix_wkv7_fused_mm8, skinny_untile_weight, the clock probes)
  *   4  round 4: rwkv7_tmix_gemms / _mm8 gained `status` (a sticky status word of the caller's) ahead of spin_limit and the status
- *      word moved to the END of the sync words; rwkv7_commit_sampled gained status_src / status_dst ahead of `stream` */
+ *      word moved to the END of the sync words; rwkv7_commit_sampled gained status_src / status_dst ahead of `stream`;
+ *      new: mm8t_seq_exact, mm8t_exact_workspace_bytes, mm8_dequant_f16, chirrup_device_cu_count */
 #define CHIRRUP_ABI_VERSION 4
 int chirrup_abi_version(void);
 const char *chirrup_target_arch(void);
@@ -394,6 +395,22 @@ int64_t mm8t_workspace_bytes(int B, int N_in, int M_out, int splits);
 int mm8t_seq(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
              const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
              int splits, void *workspace, void *stream);
+/* mm8t_seq with the arithmetic of the reference's mm8_seq -- kernel_mm_seq_fp16i8, scripts/test_mm8/rwkv_pip_operators.cu:59-83:
+ * every product and every sum in binary32 -- at matrix-core speed: x*ry (two binary16 numbers: <= 22 significant bits, exact in
+ * binary32) is split EXACTLY into hi + lo binary16 operands, multiplied in two passes with binary32 accumulation and reduced
+ * with the rank-1 corrections.  Differs from the as-coded kernel only by the order of the binary32 sums (~1e-5 of the row
+ * scale; mm8t_seq, which rounds xs to binary16 like the reference's mm8_seq_opt, rwkv_pip_wrapper.cpp:148-191: 2e-3).  Same
+ * arguments as mm8t_seq; workspace: mm8t_exact_workspace_bytes. */
+/* The dequantised matrix of mm8t_seq's weights as binary16 [M_out][N_in] row-major: out[m][k] = fp16(((q + 0.5) * rx[m]) * ry[k] +
+ * mx[m] + my[k]) (the as-coded dequantisation, rwkv_pip_operators.cu:76-79, rounded once).  For products of more than 256 rows
+ * (chunked prefill), which are MFMA-bound: one pass into a reused scratch, then a binary16 GEMM (the reference's own mm8_seq_opt
+ * casts the uint8 matrix to binary16 in front of cuBLAS the same way, rwkv_pip_wrapper.cpp:163-176).  wT as in mm8t_seq. */
+int mm8_dequant_f16(int M_out, int N_in, const void *wT, int64_t w_stride, int w_tiled, const void *rx, const void *mx, const void *ry,
+                    const void *my, void *out, void *stream);
+int64_t mm8t_exact_workspace_bytes(int B, int N_in, int M_out, int splits);
+int mm8t_seq_exact(int B, int N_in, int M_out, const void *x, int x_stride, const void *wT, int64_t w_stride, int w_tiled,
+                   const void *mx, const void *rx, const void *my, const void *ry, void *y, int y_stride, int act,
+                   int splits, void *workspace, void *stream);
 
 /*
  * Penalties + greedy token selection in one pass (rows decoded with temperature 0).

@@ -62,23 +62,81 @@ def test_mm8_seq_op_reaches_the_mfma_kernel(oracle, B, N, M):
     t = [torch.from_numpy(z).cuda() for z in (x, q, mx, rx, my, ry)]
     scale = np.abs(want).max()
     outs = []
-    for fn in (torch.ops.rwkv_pip.mm8_seq, torch.ops.rwkv_pip.mm8_seq_opt, ops.mm8_seq_stateless):
+    for fn in (torch.ops.rwkv_pip.mm8_seq_opt, ops.mm8_seq_stateless, torch.ops.rwkv_pip.mm8_seq):
         y = torch.full((B, M), float("nan"), dtype=torch.float16, device="cuda")
         fn(B, N, M, *t, y)
         got = y.cpu().numpy().astype(np.float32)
         assert np.allclose(got, want, rtol=2e-3, atol=2e-3 * scale), float(np.abs(got - want).max() / scale)
         outs.append(y)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # same packed bytes, same kernel
+    assert torch.equal(outs[0], outs[1])      # mm8_seq_opt and the stateless C entry: same packed bytes, same one-pass kernel
     # the pack is cached per weight tensor and follows in-place updates of it
     n_entries = len(ops._MM8_PACK_CACHE)
     y = torch.empty((B, M), dtype=torch.float16, device="cuda")
-    ops.mm8_seq(B, N, M, *t, y)
+    ops.mm8_seq_opt(B, N, M, *t, y)
     assert len(ops._MM8_PACK_CACHE) == n_entries and torch.equal(y, outs[0])
     t[1].add_(1)                                                                  # wraps 255 -> 0: a different matrix
-    ops.mm8_seq(B, N, M, *t, y)
+    ops.mm8_seq_opt(B, N, M, *t, y)
     q2 = t[1].cpu().numpy()
     want2 = oracle.mm8_seq(x, q2, mx, rx, my.reshape(-1, 1), ry.reshape(-1, 1)).astype(np.float32)
     assert np.allclose(y.cpu().numpy().astype(np.float32), want2, rtol=2e-3, atol=2e-3 * np.abs(want2).max())
+
+
+@pytest.mark.parametrize("B,N,M", [(4, 256, 512), (33, 512, 128), (200, 4096, 1024), (200, 1024, 4096), (300, 512, 256)])
+def test_mm8_seq_under_its_own_name_has_the_reference_kernels_arithmetic(oracle, B, N, M):
+    """VERDICT r3 "missing" item 5: torch.ops.rwkv_pip.mm8_seq must behave like the reference's kernel of THAT name
+    (kernel_mm_seq_fp16i8, rwkv_pip_operators.cu:59-83: the as-coded expression, binary32 throughout), not like its half-precision
+    optimised form.  The op now multiplies the EXACT hi + lo split of x*ry in two matrix-core passes (mm8t_seq_exact): against the
+    as-coded oracle (oracle_mm8_seq, sequential binary32 sums) the binary16 results are equal bit for bit except where the two
+    summation orders straddle a rounding boundary -- never more than one ulp, on a small fraction of the elements; the one-pass
+    split form (mm8_seq_opt) is 30-100x further away."""
+    from chirrup_amd import ops
+    from util import record_parity
+
+    ops.register_torch_ops()
+    x, q, mx, rx, my, ry = _quantised_case(B, N, M, seed=2 * B + N + M)
+    want = oracle.mm8_seq(x, q, mx, rx, my.reshape(-1, 1), ry.reshape(-1, 1))
+    t = [torch.from_numpy(z).cuda() for z in (x, q, mx, rx, my, ry)]
+    y = torch.full((B, M), float("nan"), dtype=torch.float16, device="cuda")
+    torch.ops.rwkv_pip.mm8_seq(B, N, M, *t, y)
+    y_opt = torch.full((B, M), float("nan"), dtype=torch.float16, device="cuda")
+    torch.ops.rwkv_pip.mm8_seq_opt(B, N, M, *t, y_opt)
+    got, opt = y.cpu().numpy(), y_opt.cpu().numpy()
+    w32 = want.astype(np.float32)
+    scale = float(np.abs(w32).max())
+    big = np.abs(w32) >= scale / 16                       # (a near-zero output is many of ITS ulps away after one binary32 rounding difference)
+    ulp = np.abs(bits(got).astype(np.int32) - bits(want).astype(np.int32))
+    ulp_opt = np.abs(bits(opt).astype(np.int32) - bits(want).astype(np.int32))
+    err = float(np.abs(got.astype(np.float32) - w32).max() / scale)
+    err_opt = float(np.abs(opt.astype(np.float32) - w32).max() / scale)
+    differ, differ_opt = float((ulp != 0).mean()), float((ulp_opt != 0).mean())
+    record_parity(f"rwkv_pip::mm8_seq ({B}, {N}, {M}) vs oracle_mm8_seq", tensor="y, fraction of elements not bit-equal", bar=0.05, bar_on="fraction",
+                  fraction=differ, one_pass_split_form_fraction=differ_opt, rel_linf=err, one_pass_split_form_rel_linf=err_opt,
+                  max_ulps_of_elements_above_scale_over_16=int(ulp[big].max()))
+    assert int(ulp[big].max()) <= 1, int(ulp[big].max())          # never more than one ulp where an ulp means something
+    assert differ <= 0.05, differ                                  # measured 1.2-2.8 % (profiles/r04_parity_errors.txt)
+    assert err <= 2.0 ** -10, err                                  # i.e. one binary16 ulp of the largest output
+    assert differ < 0.5 * differ_opt, (differ, differ_opt)         # the one-pass split form (xs rounded to binary16) is off on most elements
+
+
+def test_mm8_dequant_is_the_as_coded_dequantisation_rounded_once():
+    """mm8_dequant_f16 (what a chunked-prefill forward multiplies through the library GEMM): out[m][k] = fp16(((q + 0.5) * rx[m]) *
+    ry[k] + mx[m] + my[k]) -- rwkv_pip_operators.cu:76-79 left to right in binary32 -- from the tile images and from row-major
+    uint8, bit for bit."""
+    from chirrup_amd import ops
+
+    rng = np.random.default_rng(5)
+    for M, N in ((256, 128), (512, 1024), (384, 192)):
+        qT = rng.integers(0, 256, (M, N)).astype(np.uint8)
+        mx, rx = (rng.standard_normal(M) * 0.05).astype(F16), (rng.uniform(0.5, 1.5, M) / 16).astype(F16)
+        my, ry = (rng.standard_normal(N) * 0.05).astype(F16), (rng.uniform(0.5, 1.5, N) / 16).astype(F16)
+        f = np.float32
+        want = (((qT.astype(f) + f(0.5)) * rx.astype(f)[:, None]) * ry.astype(f)[None, :] + mx.astype(f)[:, None] + my.astype(f)[None, :]).astype(F16)
+        tq = torch.from_numpy(qT).cuda()
+        vec = [torch.from_numpy(v).cuda() for v in (mx, rx, my, ry)]
+        got_rm = ops.mm8_dequant(tq, *vec, tiled=False)
+        got_t = ops.mm8_dequant(ops.tile_weight_u8(tq), *vec, tiled=True, out=torch.empty(M * N + 64, dtype=torch.float16, device="cuda"))
+        assert np.array_equal(bits(got_rm.cpu().numpy()), bits(want))
+        assert np.array_equal(bits(got_t.cpu().numpy()), bits(want))
 
 
 def test_mm8_seq_op_at_the_ffn_key_shape():
@@ -95,13 +153,17 @@ def test_mm8_seq_op_at_the_ffn_key_shape():
     t = [torch.from_numpy(z).cuda() for z in (x, q, mx, rx, my, ry)]
     scale = np.abs(want).max()
     outs = []
-    for fn, tol in ((ops.mm8_seq, 2e-3), (ops.mm8_seq_stateless, 2e-3), (ops.mm8_seq_direct, 1e-3)):
+    for fn, tol in ((ops.mm8_seq_opt, 2e-3), (ops.mm8_seq_stateless, 2e-3), (ops.mm8_seq, 1e-3), (ops.mm8_seq_direct, 1e-3)):
         y = torch.full((B, M), float("nan"), dtype=torch.float16, device="cuda")
         fn(B, N, M, *t, y)
         got = y.cpu().numpy().astype(np.float32)
         assert np.allclose(got, want, rtol=tol, atol=tol * scale), (fn.__name__, float(np.abs(got - want).max() / scale))
         outs.append(y)
     assert torch.equal(outs[0], outs[1])              # same packed bytes, same kernel
+    # the two-pass exact split under the reference's name and the as-coded scalar kernel: one ulp apart at most, on a few elements
+    d = (outs[2].view(torch.int16).int() - outs[3].view(torch.int16).int()).abs()
+    big = outs[3].abs() >= outs[3].abs().max() / 16
+    assert int(d[big].max()) <= 1 and float((d != 0).float().mean()) <= 0.05
 
 
 @pytest.mark.parametrize("N,M", [(64, 256), (300, 700), (1024, 4096)])
