@@ -117,11 +117,7 @@ __device__ __forceinline__ void ln_row(const f16 *x, const f16 *__restrict__ del
                     for (int u = 0; u < PL; u++) {
                         if (in_row && s0 + u < dsplits) {
                             p[u][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8));
-#ifdef EXP_HALF_PLANES
-                            p[u][1] = p[u][0];   // TIMING EXPERIMENT ONLY (wrong results): half the partial bytes are read
-#else
                             p[u][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dpart + (s0 + u) * dsplit_stride + c * 8 + 4));
-#endif
                         }
                     }
                     if (q_S && !q_ready) {             // (uniform: every lane of the workgroup gets here, in_row or not)

@@ -411,9 +411,6 @@ __device__ __forceinline__ void store_staged(const float *stage, const int M, co
             for (int e = 0; e < 4; e++) o[e] = (f16)apply_act(t.bias ? v[e] + (float)t.bias[n + e] : v[e], t.act);
             *reinterpret_cast<f16x4 *>(t.Y + (int64_t)m * t.ldy + n) = o;
         } else {
-#ifdef EXP_HALF_PLANES
-            if (c4 & 1) continue;          // TIMING EXPERIMENT ONLY (wrong results): half the partial bytes leave the workgroup
-#endif
 #if RING_ABLATE & 8
             __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(t.part + ((int64_t)kslice * plane_rows + m) * t.Np + n));
 #else
