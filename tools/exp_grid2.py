@@ -1,4 +1,4 @@
-"""2 x 2 wave grid of the ring GEMM (skinny_gemm.hip: RING_GRID2) against the strip layout: the ffn.key / ffn.value launches of a
+"""2 x 2 wave grid of the ring GEMM (a compile-time variant of skinny_gemm.hip measured in round 4, profiles/r04_gemm_2x2_wave_grid_u8.txt; the tool is a digest + timing A/B of any two library builds) against the strip layout: the ffn.key / ffn.value launches of a
 7.2B decode step at `rows` rows, uint8 and binary16 weights -- a digest of every launch's output (the layouts must agree bit for
 bit) and us per launch (graph replay over rotating weights).  Run once per library build (CHIRRUP_AMD_LIB=...)."""
 import hashlib
