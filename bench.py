@@ -742,6 +742,9 @@ def main():
     grouped = world > 1 or bool(os.environ.get("CHIRRUP_BENCH_FORCE_DIST"))   # the latter: 1-rank RCCL rehearsal
     if grouped:
         backend = os.environ.get("CHIRRUP_BENCH_BACKEND", "nccl")     # "nccl" IS RCCL on ROCm; gloo for rehearsals
+        if backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit(f"bench.py --gpus {world}: this node has {torch.cuda.device_count()} GPU(s) and RCCL refuses two ranks on one device "
+                             "(\"Duplicate GPU detected\"); for a rehearsal of the launch path on fewer GPUs set CHIRRUP_BENCH_BACKEND=gloo")
         # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries the one JSON
         # line of the contract, so the banner is sent to stderr (file-descriptor level: it is written from C).
         sys.stdout.flush()
