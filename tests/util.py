@@ -91,7 +91,27 @@ def record_parity(case, **fields):
         pass
 
 
+_BARS = None
+
+
+def tight_bar(case, name, ceiling):
+    """The bar a measurement is held to: tests/golden/parity_bars.json holds, per (case, tensor), 1.25 x the error measured on an
+    MI355X with this round's kernels (written by `python tools/parity_report.py --write-bars` from the log of a full -m gpu run;
+    the same log is committed as profiles/r04_parity_errors.txt) -- never above `ceiling`, the bar the test's own argument gives
+    (north_star's 1e-3, a noise floor of two CPU evaluations, ...).  VERDICT r3 item 2: every bar <= 1.25 x its measurement."""
+    global _BARS
+    if _BARS is None:
+        import json
+        import os
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_bars.json")
+        _BARS = json.load(open(path)) if os.path.exists(path) else {}
+    b = _BARS.get(f"{case}|{name}")
+    return ceiling if b is None else min(ceiling, b)
+
+
 def check_bar(case, name, stats, bar, key="rel_linf"):
-    """Record (measurement, bar) and assert measurement <= bar."""
+    """Record (measurement, bar) and assert measurement <= bar (bar = tight_bar(...): 1.25 x the committed measurement, at most `bar`)."""
+    bar = tight_bar(case, name, bar)
     record_parity(case, tensor=name, bar=bar, bar_on=key, **stats)
     assert stats[key] <= bar, (case, name, key, stats[key], bar)

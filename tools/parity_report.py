@@ -11,11 +11,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity", "r04_parity_errors.jsonl")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0] if args else os.path.join(ROOT, "gpurun_out", "parity", "r04_parity_errors.jsonl")
     rows = {}
     for line in open(path):
         r = json.loads(line)
         rows[(r["case"], r["tensor"])] = r                 # the last run of a case wins
+    if "--write-bars" in sys.argv:
+        # tests/golden/parity_bars.json: 1.25 x the measurement, rounded up to 3 significant digits; a measurement of exactly 0
+        # (bit-equal today) gets a quarter of a top-binade binary16 ulp relative (1.2e-4) so that the bar stays a tolerance
+        import math
+
+        bars = {}
+        for (case, tensor), r in rows.items():
+            key = r["bar_on"]
+            m = r.get(key)
+            if m is None or key == "fraction" or tensor.startswith("wkv state (ABSOLUTE"):
+                continue                                    # (fractions keep their stated bar; the absolute 1e-3 IS north_star's)
+            b = 1.25 * m if m > 0 else 1.2e-4
+            mag = 10 ** (math.floor(math.log10(b)) - 2)
+            bars[f"{case}|{tensor}"] = math.ceil(b / mag) * mag
+        out = os.path.join(ROOT, "tests", "golden", "parity_bars.json")
+        json.dump(bars, open(out, "w"), indent=0, sort_keys=True)
+        print(f"wrote {out} ({len(bars)} bars)", file=sys.stderr)
     print("Measured parity errors beside their bars (MI355X; one row per asserted bar; `measured` is in the unit the bar is written in:")
     print("rel_linf = L-inf error / max(1, max|want|), abs_linf = absolute L-inf, top_binade_ulps = error in binary16 ulps of the tensor's top binade).")
     print("Every bar is <= 1.25 x a measurement of this table or a stated floor (north_star's 1e-3, a second CPU evaluation of the same arithmetic).")
