@@ -109,11 +109,11 @@ def test_mm8_seq_under_its_own_name_has_the_reference_kernels_arithmetic(oracle,
     err = float(np.abs(got.astype(np.float32) - w32).max() / scale)
     err_opt = float(np.abs(opt.astype(np.float32) - w32).max() / scale)
     differ, differ_opt = float((ulp != 0).mean()), float((ulp_opt != 0).mean())
-    record_parity(f"rwkv_pip::mm8_seq ({B}, {N}, {M}) vs oracle_mm8_seq", tensor="y, fraction of elements not bit-equal", bar=0.05, bar_on="fraction",
+    record_parity(f"rwkv_pip::mm8_seq ({B}, {N}, {M}) vs oracle_mm8_seq", tensor="y, fraction of elements not bit-equal", bar=0.036, bar_on="fraction",
                   fraction=differ, one_pass_split_form_fraction=differ_opt, rel_linf=err, one_pass_split_form_rel_linf=err_opt,
                   max_ulps_of_elements_above_scale_over_16=int(ulp[big].max()))
     assert int(ulp[big].max()) <= 1, int(ulp[big].max())          # never more than one ulp where an ulp means something
-    assert differ <= 0.05, differ                                  # measured 1.2-2.8 % (profiles/r04_parity_errors.txt)
+    assert differ <= 0.036, differ                                 # 1.25 x the largest measured 2.81 % (profiles/r04_parity_errors.txt: 1.2-2.8 %)
     assert err <= 2.0 ** -10, err                                  # i.e. one binary16 ulp of the largest output
     assert differ < 0.5 * differ_opt, (differ, differ_opt)         # the one-pass split form (xs rounded to binary16) is off on most elements
 
