@@ -59,6 +59,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mm8-leg", action="store_true", help="skip the second (uint8 FFN) model of the mm8 object")
     p.add_argument("--no-engine-leg", action="store_true", help="skip the Worker-loop measurement of the engine object")
+    p.add_argument("--serving-fill-first", action="store_true", help="also run the serving leg with Worker.prefill_when_underfilled (not the reference's cadence), reported as serving_fill_first")
     p.add_argument("--no-serving-leg", action="store_true", help="skip the serving run on SURVEY 8d's inputs (64-token prompts, 256 new tokens per request)")
     p.add_argument("--no-penalties", action="store_true", help="plain arg-max instead of the worker's penalty tables + commit (round 1's step)")
     p.add_argument("--no-tiled", action="store_true", help="without the tile-image weight copies of the ring GEMM (A/B)")
@@ -631,7 +632,7 @@ def prefill_chunk_ms(model, dev, n_seq=25, T=100, iters=3):
     return e0.elapsed_time(e1) / iters
 
 
-def serving_run(model, B, dev, rank, prompt_len=64, new_tokens=256):
+def serving_run(model, B, dev, rank, prompt_len=64, new_tokens=256, fill_first=False):
     """The serving loop on SURVEY.md section 8d's inputs: B requests arrive at once, each a `prompt_len`-token prompt (ids from
     randint(1, 65536), seed 1234 + rank) followed by `new_tokens` greedy tokens -- admission, CHUNKED PREFILL under the reference's
     cadence (at most B/8 sequences per chunk, one chunk every decode_prefill_ratio = 5 decode iterations: chirrup/worker.py:143,
@@ -665,6 +666,7 @@ def serving_run(model, B, dev, rank, prompt_len=64, new_tokens=256):
     cfg = ModelLoadConfig(model_path="synthetic", vocab_path="none", vocab_size=65536, head_size=64)
     tq, mq = queue.Queue(), queue.Queue()
     w = Worker(f"worker_{rank}", [dev.index], cfg, tq, mq, None, batch_size=B + 1, model=model, tokenizer=Tok())
+    w.prefill_when_underfilled = fill_first
     w._init_worker()
     # warm-up outside the timed region: the graph buckets and library GEMM plans this run will use (one short request per bucket size)
     g = torch.Generator().manual_seed(99 + rank)
@@ -816,12 +818,13 @@ def main():
     fused_core = bool(getattr(model, "fuse_tmix_core", False) and model.fused)
     wkv_ms = wkv7_event_timing(model, state, B, fused=fused_core)
     wkv_op_ms = wkv7_event_timing(model, state, B, fused=False)
-    engine_dt = serving = None
+    engine_dt = serving = serving_ff = None
     if not a.no_engine_leg and not a.no_graph and not a.no_fused:
         del state
         engine_steps = max(a.steps, 60)              # (20 iterations are 0.14 s: box-to-box clock drift showed up as 1.00-1.035x)
         engine_dt = engine_iterations(model, B, a, dev, rank, engine_steps)
         serving = serving_run(model, B, dev, rank) if not a.no_serving_leg else None
+        serving_ff = serving_run(model, B, dev, rank, fill_first=True) if (a.serving_fill_first and not a.no_serving_leg) else None
         state = make_state(model, B)
     prefill_ms = prefill_chunk_ms(model, dev) if (rank == 0 and not a.no_serving_leg and not a.no_fused) else None
     gemm_t = gemm_shape_timings(model, B) if (rank == 0 and not os.environ.get("CHIRRUP_BENCH_NO_GEMM_LEG")) else {}      # (the env switch: per-kernel profiles of the step alone)
@@ -907,6 +910,12 @@ def main():
                               "tpot_ms_median": round(serving["tpot_ms_median"], 3), "tps_per_request_median": round(1e3 / serving["tpot_ms_median"], 2),
                               "ttft_ms_median": round(serving["ttft_ms_median"], 1), "ttft_ms_max": round(serving["ttft_ms_max"], 1),
                               "decode_only_bound_s": round(n_new * ms_per_step / 1e3, 4)}
+        if serving_ff is not None:
+            out["serving_fill_first"] = {"what": "the serving leg with Worker.prefill_when_underfilled = True (a prefill chunk in every iteration while fewer than half of the slots decode; NOT the reference's cadence)",
+                                         "seconds": round(serving_ff["seconds"], 4), "generated_tokens_per_s": round(world * B * 256 / serving_ff["seconds"], 1),
+                                         "iterations": serving_ff["iterations"], "prefill_chunks": serving_ff["prefill_chunks"],
+                                         "tpot_ms_median": round(serving_ff["tpot_ms_median"], 3), "ttft_ms_median": round(serving_ff["ttft_ms_median"], 1),
+                                         "ttft_ms_max": round(serving_ff["ttft_ms_max"], 1)}
         if prefill_ms is not None:
             out["prefill"] = {"what": "one chunked-prefill forward as the worker issues it at bsz 200: 25 sequences x 100 tokens (chirrup/worker.py:744-776), logits discarded",
                               "ms_per_chunk": round(prefill_ms, 2), "prompt_tokens_per_s": round(2500 / prefill_ms * 1e3, 0),

@@ -116,6 +116,10 @@ class Worker:
         self.max_forward_seq_len_per_forward = 100
         self.seq_forward_count_down = 0
         self.decode_prefill_ratio = 5
+        # NOT the reference's policy (off by default): while fewer than half of the slots are decoding, run a prefill chunk in
+        # EVERY iteration instead of every decode_prefill_ratio-th -- a batch that arrives at once reaches full width after
+        # n_chunks iterations instead of 5 x n_chunks (bench.py --serving-fill-first)
+        self.prefill_when_underfilled = False
         self.shutdown_flag = False
         self.loop_time_recorder = deque(maxlen=10)
         self.iterations = 0
@@ -558,7 +562,7 @@ class Worker:
             self.seq_forward_count_down -= 1
         else:
             self.seq_forward_count_down = 0
-        if self.seq_forward_count_down < 1 and seq:
+        if seq and (self.seq_forward_count_down < 1 or (self.prefill_when_underfilled and 2 * len(dec) < self.max_batch_size)):
             self._run_forward_seq(seq)
             self.seq_forward_count_down = max(1, self.decode_prefill_ratio)
         if self.run_ahead:

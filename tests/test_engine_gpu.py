@@ -205,3 +205,64 @@ def test_process_mode_prefix_states_never_leave_hbm(tmp_path):
     # interval inside someone else's timed region: the most likely cause of round 3's 486-us mm8 timing)
     left = [t.name for t in threading.enumerate() if t.name.startswith("chirrup:") and t.is_alive()]
     assert not left, left
+
+
+def test_openai_routes_over_the_real_worker_on_the_gpu(tmp_path):
+    """SURVEY 8 f/4 on hardware: checkpoint file -> worker PROCESS on the GPU with an HBM arena -> AsyncEngineCore ->
+    chirrup_amd.web_service: a chat completion streamed and as one body, the second identical request served from the cached prefix
+    state (an arena row address: the state never leaves HBM), both equal to the engine's own stream for the same tokens."""
+    import json
+
+    import httpx
+
+    from chirrup_amd.core_structure import ModelLoadConfig
+    from chirrup_amd.engine_core import AsyncEngineCore
+    from chirrup_amd.remote_arena import RemoteStateRef
+    from chirrup_amd.web_service import ChatMessage, chat_prompt, create_app
+
+    d = np.load(os.path.join(G, "model_L2_C128.npz"))
+    zd = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w:")}
+    ckpt = os.path.join(tmp_path, "tiny.pth")
+    torch.save(zd, ckpt)
+    vocab = os.path.join(G, "mini_vocab.txt")
+    msgs = [{"role": "user", "content": "the quick brown fox jumps over the lazy dog"}]
+    req = {"model": "rwkv-latest", "messages": msgs, "temperature": 0.0, "top_p": 0.0, "presence_penalty": 0.0, "frequency_penalty": 0.0,
+           "penalty_decay": 1.0, "max_tokens": 8, "stop": []}
+
+    async def main():
+        eng = AsyncEngineCore(worker_mode="process", state_arena_rows=4)
+        cfg = ModelLoadConfig(model_path=ckpt, vocab_path=vocab, vocab_size=320, head_size=64)
+        await asyncio.wait_for(eng.init(worker_num=1, model_config=cfg, batch_size=4), 300)
+        prompt, pad = chat_prompt([ChatMessage(**m) for m in msgs], req["model"])
+        toks = [0] + eng.tokenizer.encode(prompt)
+        kw = dict(temperature=0.0, top_p=0.0, frequency_penalty=0.0, presence_penalty=0.0, penalty_decay=1.0, max_tokens=8)
+        c = eng.completion(prompt, prefill_tokens=list(toks), **kw)                 # the engine's own stream (default stop tokens, like the route)
+        want_text = "".join([ev[2] async for ev in c if ev[0] == "token"])
+        app = create_app(eng, state_cache_size=2)
+        outs = []
+        async with httpx.AsyncClient(transport=httpx.ASGITransport(app=app), base_url="http://t") as cl:
+            assert (await cl.get("/health")).json()["model_loaded"] is True
+            for stream in (False, True, True):
+                r = await cl.post("/v1/chat/completions", json=dict(req, stream=stream), timeout=120)
+                assert r.status_code == 200
+                if stream:
+                    chunks = [json.loads(ln[6:]) for ln in r.text.split("\n\n") if ln.startswith("data: ") and ln != "data: [DONE]"]
+                    outs.append("".join(ch["choices"][0]["delta"].get("content", "") + ch["choices"][0]["delta"].get("reasoning_content", "")
+                                        for ch in chunks))
+                else:
+                    m = r.json()["choices"][0]["message"]
+                    outs.append(m["content"] + m["reasoning_content"])
+            cache = app.state.state_cache
+            assert len(cache) == 1                                                   # cached once, by the first request; hits afterwards
+            (key,) = cache.keys()
+            assert list(key) == toks[:len(toks) - pad]
+            _, st, n_hit = cache.check(list(toks))
+            assert isinstance(st, RemoteStateRef) and n_hit == len(toks) - pad       # an arena row address, no tensor
+            st.release()
+        eng.shutdown()
+        return want_text, outs
+
+    want_text, outs = asyncio.run(main())
+    # the `\n\n` rule of the splitter may end the visible answer early; whatever is shown is a prefix of the engine's text
+    assert all(want_text.startswith(o) or o == want_text for o in outs), (want_text, outs)
+    assert outs[0] == outs[1] == outs[2]                                             # uncached, streamed, and from the cached prefix: one answer
