@@ -80,7 +80,7 @@ def test_bench_gpus_2_without_a_launcher_makes_two_ranks():
     assert len(lines) == 1
     j = lines[0]
     assert j["n_gpus"] == 2 and j["world_size_seen"] == 2 and j["backend"] == "gloo" and len(j["per_rank_ms_per_step"]) == 2
-    assert j["per_rank_ms_per_step"][1] > j["per_rank_ms_per_step"][0] * 1.5            # rank 1 sleeps twice as long ...
+    assert j["per_rank_ms_per_step"][1] > j["per_rank_ms_per_step"][0] * 1.2            # rank 1 sleeps twice as long ...
     assert j["ms_per_step"] >= max(j["per_rank_ms_per_step"]) * 0.999                   # ... and the line carries the slower rank's time
 
 
