@@ -611,6 +611,45 @@ def engine_iterations(model, B, a, dev, rank, steps):
     return dt
 
 
+def launches_per_layer(model, B):
+    """Kernel-launching C-ABI calls of ONE decode layer, counted on an eager step at the library handle (every entry point of
+    libchirrup_amd.so that takes a stream): (calls of a step with L layers - calls of the same step with one layer) / (L - 1).
+    A grouped GEMM entry with a split counts once although it launches its reduce too (7.2B / bsz 200 has none)."""
+    from chirrup_amd import lib as _lib
+
+    L_ = _lib.load()
+    skip = ("bytes", "words", "word", "count", "version", "arch", "parts", "splits", "_ok", "probe", "counters")
+    names = [n for n in _lib.SIGNATURES if not any(k in n for k in skip)]
+    calls = [0]
+    originals = {n: getattr(L_, n) for n in names}
+
+    def proxy(fn):
+        def call(*a):
+            calls[0] += 1
+            return fn(*a)
+        return call
+
+    st = model.generate_zero_state(B)
+    tok = torch.ones((B, 1), dtype=torch.long, device=model.device)
+    for n, fn in originals.items():
+        setattr(L_, n, proxy(fn))
+    try:
+        model.forward_seq_batch(tok, st)
+        total = calls[0]
+        layers, model._layers = model._layers, model._layers[:1]
+        try:
+            calls[0] = 0
+            model.forward_seq_batch(tok, [st[0][:1], st[1][:1], st[2]])
+            one = calls[0]
+        finally:
+            model._layers = layers
+    finally:
+        for n, fn in originals.items():
+            setattr(L_, n, fn)
+    L = len(model._layers)
+    return round((total - one) / (L - 1), 2) if L > 1 else None
+
+
 def prefill_chunk_ms(model, dev, n_seq=25, T=100, iters=3):
     """One chunked-prefill forward as the worker issues it at bsz 200 (chirrup/worker.py:744-776: at most batch_size/8 = 25
     sequences x at most 100 tokens through forward_slots, logits discarded): ms per chunk from HIP events."""
@@ -827,6 +866,10 @@ def main():
         serving_ff = serving_run(model, B, dev, rank, fill_first=True) if (a.serving_fill_first and not a.no_serving_leg) else None
         state = make_state(model, B)
     prefill_ms = prefill_chunk_ms(model, dev) if (rank == 0 and not a.no_serving_leg and not a.no_fused) else None
+    try:
+        n_launch = launches_per_layer(model, B) if (rank == 0 and not a.no_fused) else None
+    except Exception:                                    # noqa: BLE001 -- a diagnostic: never the reason a bench line is missing
+        n_launch = None
     gemm_t = gemm_shape_timings(model, B) if (rank == 0 and not os.environ.get("CHIRRUP_BENCH_NO_GEMM_LEG")) else {}      # (the env switch: per-kernel profiles of the step alone)
     clocks = clock_probes(model, B) if (rank == 0 and not a.no_fused) else None
     mm8_obj = None
@@ -872,6 +915,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16" if not (a.mm8 or a.mm8_all) else ("f16 (u8 ffn weights, mm8)" if not a.mm8_all else "f16 (u8 weights for R/K/V/O, ffn and head: mm8)"), "data": "synthetic",
             "tps_per_request": round(1e3 / ms_per_step, 2),
+            "launches_per_layer": n_launch,
             "world_size_seen": dist.get_world_size() if grouped else 1,
             "collective_backend": (dist.get_backend() if grouped else None),
             "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
