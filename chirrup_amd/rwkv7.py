@@ -270,6 +270,9 @@ class RWKV_x070:
         self.skinny_min_rows = 1                         # ... at every batch size (7.2B: -20 % at 32 rows, -23 % at 1 row vs the library)
         self.skinny_min_embd = skinny_min_embd           # ... at every model size (1.5B bsz 32: -26 %, 0.1B bsz 1: -34 % vs the library)
         self.skinny_lora_up = True                       # LoRA up-projections (+bias in the epilogue) as one batched launch of the same kernel
+        self.tune_prefill_gemms = True                   # library GEMMs of a chunked-prefill forward: whole or as two row halves, measured once per shape (_mm_nt)
+        self.tune_mm_min_rows = 512                      # (below: the single call always won the sweep)
+        self._mm_plan: Dict[tuple, str] = {}
         self.mm8_prefill_dequant = True                  # uint8 ffn above 256 rows: dequantise into a binary16 scratch + library GEMM (False: 256-row blocks through the ring kernel)
         self.mm8_fused_key = True                        # mm8 ffn.key: corrections, relu^2 and ffn.value's prologue in the GEMM epilogue (>= 128 rows)
         self.mm8_pair_key = True                         # ... and at few rows: the K split reduced inside the launch, the same epilogue (no mm8_reduce_rows launch)
@@ -344,6 +347,56 @@ class RWKV_x070:
             if not self.keep_row_major:
                 self._drop_row_major()
             torch.cuda.empty_cache()
+
+    def _mm_nt(self, x2: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> None:
+        """out [rows, N] = x2 [rows, K] @ w [N, K]^T through the library, in the formulation the library runs fastest for this shape:
+        ONE call, or two calls over the two halves of the rows.  hipBLASLt's own kernel choice has potholes (ffn.value at 1575-1600
+        rows: 394-421 us whole, 262-269 us as two halves; ffn.key at 2500 rows: 377 vs 283; everywhere else the single call wins by
+        10-40 %: profiles/r04_prefill_gemm_formulations.txt), and a worker's chunk row counts vary (sequences x min(100, shortest
+        remaining prompt)), so the choice is MEASURED once per (rows, N, K) -- two timed runs of each formulation on the real operands,
+        ~2 ms, cached on the model -- not guessed.  Both formulations compute every output row from the same operands; which kernel
+        the library picks for a half may sum K in another order, i.e. the result is defined to the library's summation order, as
+        everywhere above 256 rows."""
+        rows = x2.shape[0]
+        plan = "whole"
+        if rows >= self.tune_mm_min_rows and self.tune_prefill_gemms and x2.is_cuda:
+            key = (rows, w.shape[0], w.shape[1])
+            plan = self._mm_plan.get(key)
+            if plan is None:
+                plan = "whole"
+                if not torch.cuda.is_current_stream_capturing():
+                    plan = self._mm_plan[key] = self._measure_mm(x2, w, out)
+        if plan == "whole":
+            torch.mm(x2, w.t(), out=out)
+        else:
+            half = (rows + 1) // 2
+            torch.mm(x2[:half], w.t(), out=out[:half])
+            torch.mm(x2[half:], w.t(), out=out[half:])
+
+    def _measure_mm(self, x2, w, out) -> str:
+        rows = x2.shape[0]
+        half = (rows + 1) // 2
+
+        def whole():
+            torch.mm(x2, w.t(), out=out)
+
+        def halves():
+            torch.mm(x2[:half], w.t(), out=out[:half])
+            torch.mm(x2[half:], w.t(), out=out[half:])
+
+        best, best_t = "whole", None
+        for name, fn in (("whole", whole), ("halves", halves)):
+            fn()                                          # (the library's own one-time set-up for the shape)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            fn()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < 0.95 * best_t:       # (the single call unless two halves win by more than 5 %)
+                best, best_t = name, t
+        return best
 
     def _mm8_scratch(self, numel: int):
         """Two binary16 scratch matrices of `numel` elements (ffn.key's and ffn.value's dequantised forms during a chunked-prefill
@@ -816,16 +869,11 @@ class RWKV_x070:
                 sK, sV = self._mm8_scratch(4 * C * C)
                 wK16 = ops.mm8_dequant(*lw.f_K8, tiled=lw.f8_tiled, out=sK)          # [4C, C]
                 kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
-                kv2, xin = kf.view(rows, 4 * C), kin[0].view(rows, C)
-                if rows >= self.split_rows_min:
-                    half = (rows + 1) // 2
-                    torch.mm(xin[:half], wK16.t(), out=kv2[:half])
-                    torch.mm(xin[half:], wK16.t(), out=kv2[half:])
-                else:
-                    torch.mm(xin, wK16.t(), out=kv2)
+                self._mm_nt(kin[0].view(rows, C), wK16, kf.view(rows, 4 * C))
                 ops.relu_sq_(kf)
                 wV16 = ops.mm8_dequant(*lw.f_V8, tiled=lw.f8_tiled, out=sV)          # [C, 4C]
-                delta = F.linear(kf, wV16)
+                delta = torch.empty((B, T, C), dtype=DTYPE, device=dev)
+                self._mm_nt(kf.view(rows, 4 * C), wV16, delta.view(rows, C))
             elif self.ffn_dtype == torch.int8:      # mm8 on the matrix cores, relu^2 fused into the epilogue
                 kf = ops.mm8t_linear(kin[0].view(rows, C), *lw.f_K8, act=1, tiled=lw.f8_tiled)
                 delta = ops.mm8t_linear(kf, *lw.f_V8, tiled=lw.f8_tiled).view(B, T, C)
@@ -834,16 +882,10 @@ class RWKV_x070:
                     kf = ops.skinny_linear(kin[0].view(rows, C), lw.f_K_t if lw.f_K_t is not None else lw.f_K, act=1, splits=gs["ffn_key"],
                                            row_halves=rh["ffn_key"])
                 else:
-                    if rows >= self.split_rows_min:
-                        # the library's choice for (rows x C) . (4C x C)^T runs at 0.83 PFLOP/s at 2500 rows, the same product as two
-                        # row halves at 1.16 (tools/exp_prefill_gemm.py: 404 vs 290 us; 1200 rows: 170 vs 151)
-                        kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
-                        kv2, xin = kf.view(rows, 4 * C), kin[0].view(rows, C)
-                        half = (rows + 1) // 2
-                        torch.mm(xin[:half], w_fK.t(), out=kv2[:half])
-                        torch.mm(xin[half:], w_fK.t(), out=kv2[half:])
-                    else:
-                        kf = F.linear(kin[0], w_fK)
+                    # the library's choice for (rows x C) . (4C x C)^T runs at 0.83 PFLOP/s at 2500 rows, the same product as two row
+                    # halves at 1.16 (404 vs 290 us) -- but at 1024-2200 rows the single call is the faster one: measured per shape
+                    kf = torch.empty((B, T, 4 * C), dtype=DTYPE, device=dev)
+                    self._mm_nt(kin[0].view(rows, C), w_fK, kf.view(rows, 4 * C))
                     ops.relu_sq_(kf)
                 if rows == 1 and lw.f_V_rows is not None:
                     delta = ops.rwkv_mm_sparsity(kf.view(-1), lw.f_V_rows).view(1, 1, C)
@@ -852,6 +894,9 @@ class RWKV_x070:
                     # matrix 1.35x faster than the library (53.8 vs 73.6 us at 7.2B / bsz 200);
                     # its split-K partials are summed in the prologue of the NEXT add_ln_mix (no reduce launch)
                     dparts, delta = ops.skinny_linear_partial(kf.view(rows, 4 * C), lw.f_V_t if lw.f_V_t is not None else lw.f_V.t(), gs["ffn_value"], pbuf, row_halves=rh["ffn_value"]), None
+                elif rows >= self.tune_mm_min_rows and w_fV.t().is_contiguous():
+                    delta = torch.empty((B, T, C), dtype=DTYPE, device=dev)
+                    self._mm_nt(kf.view(rows, 4 * C), w_fV.t(), delta.view(rows, C))     # (ffn.value keeps its [C, 4C] bytes: NT form)
                 else:
                     delta = kf @ w_fV
         if dparts is not None and (T > 1 and not full_output):
