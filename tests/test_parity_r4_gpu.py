@@ -180,3 +180,40 @@ def test_one_decode_step_state_within_1e_3_absolute(name, fused):
     check_bar(case, "wkv state (ABSOLUTE, north_star's 1e-3)", parity_stats(st[1].cpu().numpy(), want), 1e-3, key="abs_linf")
     check_bar(case, "logits", parity_stats(lg.cpu().numpy(), d[f"{name}:logits"]), 2e-3)
     check_bar(case, "shift state", parity_stats(st[0].cpu().numpy(), d[f"{name}:s0_out"]), 2e-3)
+
+
+def test_measured_gemm_formulation_of_a_prefill_chunk_changes_no_result_beyond_summation_order():
+    """RWKV_x070._mm_nt: above 512 rows the ffn library GEMMs run as ONE call or as two calls over the halves of the rows,
+    whichever the library runs faster for that shape (measured once, cached).  Both formulations multiply the same operands: the
+    chunk's logits and state agree to the library's summation-order noise, the plan is cached per (rows, N, K), and forcing
+    either formulation gives the measured plan's result bit for bit when it is the same formulation."""
+    from chirrup_amd.rwkv7 import RWKV_x070
+    from chirrup_amd.synth import make_state_dict
+
+    L, C, V, B, T = 2, 1024, 1024, 6, 100                    # 600 rows
+    zd = make_state_dict(L, C, V, seed=9, varied_norms=True)
+    m = RWKV_x070(types.SimpleNamespace(vocab_size=V, head_size=64, MODEL_NAME="unused"), state_dict=zd, device="cuda:0", skinny_min_embd=0)
+    toks = torch.randint(1, V, (B, T), device="cuda")
+    outs = {}
+    for name in ("measured", "whole", "halves"):
+        if name == "measured":
+            m.tune_prefill_gemms, m._mm_plan = True, {}
+        else:
+            m.tune_prefill_gemms = True
+            m._mm_plan = {k: name for k in plan}             # force one formulation for every shape seen
+        st = m.generate_zero_state(B)
+        lg = m.forward_seq_batch_seperate(toks, st)
+        if name == "measured":
+            plan = dict(m._mm_plan)
+            assert set(plan) == {(B * T, 4 * C, C), (B * T, C, 4 * C)} and set(plan.values()) <= {"whole", "halves"}
+        outs[name] = (lg.float().cpu(), st[1].float().cpu())
+    for name in ("whole", "halves"):
+        for got, want in zip(outs[name], outs["measured"]):
+            assert float((got - want).abs().max() / want.abs().max().clamp_min(1.0)) <= 2e-3
+    same = [n for n in ("whole", "halves") if all(plan[k] == n for k in plan)]
+    for n in same:                                           # the measured plan IS this formulation: identical bits
+        assert torch.equal(outs[n][0], outs["measured"][0]) and torch.equal(outs[n][1], outs["measured"][1])
+    m.tune_prefill_gemms = False                             # switched off: no plan is made, the single call runs
+    m._mm_plan = {}
+    m.forward_seq_batch_seperate(toks, m.generate_zero_state(B))
+    assert m._mm_plan == {}
