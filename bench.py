@@ -71,6 +71,7 @@ def parse():
     p.add_argument("--no-chain", action="store_true", help="LoRA up-projections as a launch of their own instead of inside the R/K/V launch, A/B only")
     p.add_argument("--mm8-pair-max-rows", type=int, default=None, help="row limit of the in-launch reduction of the mm8 ffn.key launch, tuning only")
     p.add_argument("--no-mm8-pair", action="store_true", help="mm8 ffn.key at <= 64 rows through partials + mm8_reduce_rows instead of the in-launch reduction, A/B only")
+    p.add_argument("--dense-penalties", action="store_true", help="the penalty step as a dense pass over the slots' tables (round 3) instead of over their id lists, A/B only")
     p.add_argument("--torch-commit", action="store_true", help="the sampled ids' table updates as torch ops instead of the commit kernel, A/B only")
     p.add_argument("--no-pair-reduce", action="store_true", help="K splits at <= 32 rows through the reduce launch instead of the in-launch reduction (same bits), A/B only")
     p.add_argument("--row-halves-min-rows", type=int, default=None, help="batch rows from which the row-halves GEMM launches are used, tuning only")
@@ -527,6 +528,8 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None, repeats=0):
         last_ids = torch.zeros((B,), dtype=torch.int32, device=dev)
         slots = torch.arange(B, dtype=torch.int32, device=dev)
         slots64 = slots.long()
+        # the worker's per-slot id lists (ops.PenaltyLists): the penalty step touches the listed table entries only
+        pen_lists = None if (a.dense_penalties or a.torch_commit) else ops.PenaltyLists(B, V, dev)
 
     def one_step(tok):
         """Like Worker.step() with run-ahead: the sampled ids feed the next step on the device; the host receives
@@ -535,14 +538,14 @@ def timed_decode(model, B, a, dev, rank, steps=None, warmup=None, repeats=0):
         if a.no_penalties:
             ops.penalize_argmax(logits, out=ids_dev)     # plain arg-max (temperature 0, samplers.py:195-197)
         else:
-            ops.penalize_argmax(logits, occurrence, alpha_presence, decay, freq, slots, out=ids_dev)
+            ops.penalize_argmax(logits, occurrence, alpha_presence, decay, freq, slots, out=ids_dev, lists=pen_lists)
             if a.torch_commit:                           # round 2's Worker._commit_sampled: torch ops, ~12 eager launches (A/B)
                 il = ids_dev.long()
                 last_ids.index_copy_(0, slots64, ids_dev)
                 occurrence.index_put_((slots64, il), penalty_weight[il], accumulate=True)
                 alpha_presence[slots64, il] = presence[slots64, 0]
             else:                                        # Worker._commit_sampled
-                ops.commit_sampled(ids_dev, slots, last_ids, occurrence, penalty_weight, alpha_presence, presence)
+                ops.commit_sampled(ids_dev, slots, last_ids, occurrence, penalty_weight, alpha_presence, presence, lists=pen_lists)
         i = n_steps[0] & 1
         if a.sync_ids:
             ids_host[i].copy_(ids_dev, non_blocking=False)

@@ -93,7 +93,107 @@ __global__ __launch_bounds__(kArgmaxThreads) void penalize_argmax_kernel(
     }
 }
 
+// The same step when the worker knows WHICH entries of a slot's tables can be non-zero (round 4).  A request's occurrence / presence
+// rows are zero except at the token ids it has sampled so far -- a few hundred of 65 536 -- yet the dense pass reads and writes
+// 768 KB of tables per row and step (184 MB per step at bsz 200: 42 us).  The tables stay what they are (dense, exact, no cap);
+// beside them every slot keeps the LIST of ids it has sampled (pen_list [n_slots][cap], pen_count [n_slots]; maintained by
+// commit_sampled_kernel with a bitmap so that an id is listed once).  pen_count >= 0: only the listed entries are decayed and
+// subtracted -- per element the dense kernel's arithmetic, and for every other element that arithmetic is the identity
+// (occurrence 0 * decay = 0; fp16(float(logit) - (0 + 0 * freq)) = logit) -- then the arg-max pass reads the logits alone.
+// pen_count < 0 (more distinct ids than cap): the dense pass, as before.  Bit-identical to penalize_argmax_kernel either way.
+__global__ __launch_bounds__(kArgmaxThreads) void penalize_argmax_listed_kernel(
+    const int V, f16 *__restrict__ logits, float *__restrict__ occurrence, const float *__restrict__ alpha,
+    const f16 *__restrict__ decay, const f16 *__restrict__ freq, const int32_t *__restrict__ slot_idx,
+    int32_t *__restrict__ ids, const int32_t *__restrict__ pen_list, const int32_t *__restrict__ pen_count, const int cap) {
+    __shared__ float s_val[kArgmaxThreads / 64];
+    __shared__ int s_idx[kArgmaxThreads / 64];
+    const int row = blockIdx.x;
+    const int64_t slot = slot_idx ? (int64_t)slot_idx[row] : (int64_t)row;
+    f16 *lg = logits + (int64_t)row * V;
+    float *occ = occurrence + slot * V;
+    const float *al = alpha + slot * V;
+    const float dk = (float)decay[slot], fq = (float)freq[slot];
+    const int n = pen_count[slot];
+    const bool dense = n < 0;
+    if (!dense) {
+        const int32_t *lst = pen_list + slot * cap;
+        for (int i = threadIdx.x; i < n; i += kArgmaxThreads) {
+            const int id = lst[i];
+            const float o = occ[id] * dk;
+            occ[id] = o;
+            lg[id] = (f16)((float)lg[id] - (al[id] + o * fq));
+        }
+        __threadfence_block();
+        __syncthreads();                               // the arg-max pass below reads what other lanes of this workgroup just wrote
+    }
+    float best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int c = threadIdx.x * 8; c < V; c += kArgmaxThreads * 8) {
+        f16x8 l8 = *reinterpret_cast<const f16x8 *>(lg + c);
+        if (dense) {
+            f32x4 o0 = *reinterpret_cast<const f32x4 *>(occ + c), o1 = *reinterpret_cast<const f32x4 *>(occ + c + 4);
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(al + c), a1 = *reinterpret_cast<const f32x4 *>(al + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o0[e] = o0[e] * dk;
+                o1[e] = o1[e] * dk;
+                l8[e] = (f16)((float)l8[e] - (a0[e] + o0[e] * fq));
+                l8[e + 4] = (f16)((float)l8[e + 4] - (a1[e] + o1[e] * fq));
+            }
+            *reinterpret_cast<f32x4 *>(occ + c) = o0;
+            *reinterpret_cast<f32x4 *>(occ + c + 4) = o1;
+            *reinterpret_cast<f16x8 *>(lg + c) = l8;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float v = (float)l8[e];
+            if (v > best) {
+                best = v;
+                best_i = c + e;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(best_i, o, 64);
+        if (ov > best || (ov == best && oi < best_i)) {
+            best = ov;
+            best_i = oi;
+        }
+    }
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_val[wid] = best;
+        s_idx[wid] = best_i;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kArgmaxThreads / 64; w++)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < best_i)) {
+                best = s_val[w];
+                best_i = s_idx[w];
+            }
+        ids[row] = best_i == 0x7fffffff ? 0 : best_i;
+    }
+}
+
 }  // namespace
+
+extern "C" int rwkv7_penalize_argmax_listed(int B, int V, void *logits, float *occurrence, const float *alpha_presence,
+                                            const void *penalty_decay, const void *frequency_penalty, const int32_t *slot_idx,
+                                            int32_t *ids, const int32_t *pen_list, const int32_t *pen_count, int cap, void *stream) {
+    if (B <= 0 || V <= 0 || (V & 7) || cap <= 0) return CHIRRUP_E_SHAPE;
+    if (!logits || !ids || !occurrence || !alpha_presence || !penalty_decay || !frequency_penalty || !pen_list || !pen_count) return CHIRRUP_E_NULL;
+    if ((reinterpret_cast<uintptr_t>(logits) & 15) || (reinterpret_cast<uintptr_t>(occurrence) & 15) ||
+        (reinterpret_cast<uintptr_t>(alpha_presence) & 15))
+        return CHIRRUP_E_ALIGN;
+    hipLaunchKernelGGL(penalize_argmax_listed_kernel, dim3((unsigned)B), dim3(kArgmaxThreads), 0, static_cast<hipStream_t>(stream), V,
+                       static_cast<f16 *>(logits), occurrence, alpha_presence, static_cast<const f16 *>(penalty_decay),
+                       static_cast<const f16 *>(frequency_penalty), slot_idx, ids, pen_list, pen_count, cap);
+    return (int)hipGetLastError();
+}
 
 extern "C" int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const float *alpha_presence,
                                      const void *penalty_decay, const void *frequency_penalty,
@@ -122,7 +222,9 @@ __global__ __launch_bounds__(256) void commit_sampled_kernel(const int n, const 
                                                              float *__restrict__ occurrence, const float *__restrict__ penalty_weight,
                                                              float *__restrict__ alpha, const float *__restrict__ presence,
                                                              const int64_t presence_stride, const int32_t *__restrict__ status_src,
-                                                             int32_t *__restrict__ status_dst) {
+                                                             int32_t *__restrict__ status_dst, int32_t *__restrict__ pen_list = nullptr,
+                                                             int32_t *__restrict__ pen_count = nullptr, uint32_t *__restrict__ pen_bits = nullptr,
+                                                             const int cap = 0) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     // the launch-status word of the step that produced these ids travels to the host behind them (one D2H copy for both)
     if (row == 0 && status_dst) *status_dst = status_src ? __hip_atomic_load(status_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -133,6 +235,21 @@ __global__ __launch_bounds__(256) void commit_sampled_kernel(const int n, const 
     if (id < 0 || id >= V) return;                     // (cannot be produced by the samplers; the tables are left alone)
     atomicAdd(occurrence + slot * V + id, penalty_weight[id]);     // (slots of a batch are distinct; the atomic keeps accumulate=True's meaning if not)
     alpha[slot * V + id] = presence[slot * presence_stride];
+    if (pen_list) {
+        // the slot's list of ids whose table entries may be non-zero (penalize_argmax_listed_kernel): each id once (bitmap), in
+        // sampling order; more than cap distinct ids -> count = -1, the slot falls back to the dense pass until it is reset.
+        // (atomicOr: two rows of ONE launch never share a slot in the worker; if a caller's do, the id may be listed twice --
+        // then it would be decayed twice: callers with duplicate slots in a batch must not use the listed form.)
+        uint32_t *w = pen_bits + slot * (V >> 5) + (id >> 5);
+        const uint32_t bit = 1u << (id & 31);
+        if (!(atomicOr(w, bit) & bit)) {
+            const int n = pen_count[slot];
+            if (n >= 0) {
+                if (n < cap) pen_list[slot * cap + n] = id, pen_count[slot] = n + 1;
+                else pen_count[slot] = -1;
+            }
+        }
+    }
 }
 }  // namespace
 
@@ -142,7 +259,19 @@ extern "C" int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int3
     if (n <= 0 || V <= 0 || presence_stride < 0) return CHIRRUP_E_SHAPE;
     if (!ids || !last_ids || !occurrence || !penalty_weight || !alpha_presence || !presence) return CHIRRUP_E_NULL;
     hipLaunchKernelGGL(commit_sampled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, V, ids,
-                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride, status_src, status_dst);
+                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride, status_src, status_dst, nullptr, nullptr, nullptr, 0);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rwkv7_commit_sampled_listed(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
+                                           const float *penalty_weight, float *alpha_presence, const float *presence,
+                                           int64_t presence_stride, const int32_t *status_src, int32_t *status_dst, int32_t *pen_list,
+                                           int32_t *pen_count, uint32_t *pen_bits, int cap, void *stream) {
+    if (n <= 0 || V <= 0 || (V & 31) || presence_stride < 0 || cap <= 0) return CHIRRUP_E_SHAPE;
+    if (!ids || !last_ids || !occurrence || !penalty_weight || !alpha_presence || !presence || !pen_list || !pen_count || !pen_bits) return CHIRRUP_E_NULL;
+    hipLaunchKernelGGL(commit_sampled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, V, ids,
+                       slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, presence_stride, status_src, status_dst,
+                       pen_list, pen_count, pen_bits, cap);
     return (int)hipGetLastError();
 }
 

@@ -56,6 +56,8 @@ SIGNATURES = {
     "rwkv7_lora_act": (_i, [_i, _i, _i64, _vp, _vp]),
     "rwkv7_penalize_argmax": (_i, [_i, _i] + [_vp] * 8),
     "rwkv7_commit_sampled": (_i, [_i, _i] + [_vp] * 7 + [_i64, _vp, _vp, _vp]),
+    "rwkv7_commit_sampled_listed": (_i, [_i, _i] + [_vp] * 7 + [_i64, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "rwkv7_penalize_argmax_listed": (_i, [_i, _i] + [_vp] * 9 + [_i, _vp]),
     "rwkv7_sample_topp": (_i, [_i, _i] + [_vp] * 9),
     "rwkv7_embed_rows": (_i, [_i, _i, _i, _i] + [_vp] * 6 + [_i, _vp, _vp, _vp]),
     "rwkv7_advance_elapsed": (_i, [_i, _i, _vp, _vp, _vp]),

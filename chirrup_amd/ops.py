@@ -472,10 +472,32 @@ def relu_sq_(x) -> None:
     _lib.check(rc, "rwkv7_relu_sq")
 
 
+class PenaltyLists:
+    """Per-slot lists of the token ids whose occurrence / alpha_presence entries can be non-zero (include/chirrup_amd.h:
+    rwkv7_penalize_argmax_listed): with them the penalty step touches a slot's few hundred live entries instead of reading and
+    writing its two 65 536-wide binary32 rows.  The dense tables stay the storage (exact, no cap); a slot that samples more than
+    `cap` distinct ids falls back to the dense pass until `reset(slot)`."""
+
+    def __init__(self, n_slots: int, V: int, device, cap: int = 4096):
+        if V % 32:
+            raise _lib.ChirrupAmdError("PenaltyLists: V must be a multiple of 32")
+        self.cap, self.V = int(cap), int(V)
+        self.ids = torch.zeros((n_slots, self.cap), dtype=torch.int32, device=device)
+        self.count = torch.zeros((n_slots,), dtype=torch.int32, device=device)
+        self.bits = torch.zeros((n_slots, V // 32), dtype=torch.int32, device=device)
+
+    def reset(self, slot: int) -> None:
+        """The slot starts a new request (its table rows are zeroed by the caller)."""
+        self.bits[slot].zero_()
+        self.count[slot] = 0
+
+
 def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=None, frequency_penalty=None,
-                    slot_idx=None, out=None):
+                    slot_idx=None, out=None, lists: Optional[PenaltyLists] = None):
     """Greedy rows of the worker's decode step in one kernel (see include/chirrup_amd.h):
-    logits fp16 [B,V] is penalised IN PLACE (when occurrence is given), returns int32 ids [B]."""
+    logits fp16 [B,V] is penalised IN PLACE (when occurrence is given), returns int32 ids [B].
+    lists: the slots' PenaltyLists (kept by commit_sampled(..., lists=...)): only the listed table entries are touched --
+    bit-identical logits, tables and ids."""
     if not logits.is_cuda or logits.dtype != torch.float16 or logits.dim() != 2 or not logits.is_contiguous():
         raise _lib.ChirrupAmdError("logits: expected contiguous GPU fp16 [B,V]")
     B, V = logits.shape
@@ -493,6 +515,14 @@ def penalize_argmax(logits, occurrence=None, alpha_presence=None, penalty_decay=
             raise _lib.ChirrupAmdError("penalty tables have a different row count and no slot_idx")
     if slot_idx is not None:
         _chk(slot_idx, "slot_idx", torch.int32, (B,))
+    if lists is not None and occurrence is not None:
+        if lists.V != V or lists.count.shape[0] != occurrence.shape[0]:
+            raise _lib.ChirrupAmdError("lists: built for other tables")
+        rc = _lib.load().rwkv7_penalize_argmax_listed(B, V, _ptr(logits), _ptr(occurrence), _ptr(alpha_presence), _ptr(penalty_decay),
+                                                      _ptr(frequency_penalty), _ptr(slot_idx), _ptr(out), _ptr(lists.ids), _ptr(lists.count),
+                                                      lists.cap, _stream())
+        _lib.check(rc, "rwkv7_penalize_argmax_listed")
+        return out
     rc = _lib.load().rwkv7_penalize_argmax(B, V, _ptr(logits), _ptr(occurrence), _ptr(alpha_presence), _ptr(penalty_decay),
                                            _ptr(frequency_penalty), _ptr(slot_idx), _ptr(out), _stream())
     _lib.check(rc, "rwkv7_penalize_argmax")
@@ -549,7 +579,8 @@ def copy_slot_rows(src, dst, slot_idx) -> None:
     _lib.check(rc, "rwkv7_copy_slot_rows")
 
 
-def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, status_out=None) -> None:
+def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_presence, presence, status_out=None,
+                   lists: Optional[PenaltyLists] = None) -> None:
     """ONE launch for what sampling `ids` (int32 [n]) for the slots `slot_idx` (int32 [n] or None) changes on the device
     (chirrup/worker.py:527-535): last_ids[slot] = id, occurrence[slot, id] += penalty_weight[id], alpha_presence[slot, id] =
     presence[slot, 0].  Tables fp32 [n_slots, V] contiguous, penalty_weight fp32 [V], presence fp32 [n_slots, 1] or [n_slots].
@@ -575,6 +606,11 @@ def commit_sampled(ids, slot_idx, last_ids, occurrence, penalty_weight, alpha_pr
         if not status_out.is_cuda or status_out.dtype != torch.int32 or status_out.numel() != 1:
             raise _lib.ChirrupAmdError("status_out: expected a GPU int32 element")
         st_src, st_dst = _device_status.get(status_out.device.index), status_out
+    if lists is not None:              # ... and the sampled ids join their slots' lists (PenaltyLists)
+        rc = _lib.load().rwkv7_commit_sampled_listed(n, V, _ptr(ids), _ptr(slot_idx), _ptr(last_ids), _ptr(occurrence), _ptr(penalty_weight),
+                                                     _ptr(alpha_presence), _ptr(presence), presence.stride(0), _ptr(st_src), _ptr(st_dst),
+                                                     _ptr(lists.ids), _ptr(lists.count), _ptr(lists.bits), lists.cap, _stream())
+        return _lib.check(rc, "rwkv7_commit_sampled_listed")
     rc = _lib.load().rwkv7_commit_sampled(n, V, _ptr(ids), _ptr(slot_idx), _ptr(last_ids), _ptr(occurrence), _ptr(penalty_weight),
                                           _ptr(alpha_presence), _ptr(presence), presence.stride(0), _ptr(st_src), _ptr(st_dst), _stream())
     _lib.check(rc, "rwkv7_commit_sampled")

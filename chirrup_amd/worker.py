@@ -171,6 +171,9 @@ class Worker:
         self._ids_host = ([torch.zeros((n + 1,), dtype=torch.int32).pin_memory() for _ in range(2)]     # (+ 1: the launch-status word)
                           if dev.type == "cuda" else None)
         self._launches = 0
+        # the ids each slot has sampled (ops.PenaltyLists): the penalty step then touches those entries of the dense tables only
+        self._pen_lists = (ops.PenaltyLists(n, V, dev) if (self._commit_kernel is not None and dev.type == "cuda" and V % 32 == 0
+                                                           and self._penalize_argmax is ops.penalize_argmax) else None)
         if self.state_arena is None and self.state_arena_rows > 0:
             from .state_cache import HbmStateArena
 
@@ -276,7 +279,7 @@ class Worker:
         status_out: the element behind the ids that receives the device's sticky launch-status word in the same launch."""
         if self._commit_kernel is not None:                # one launch instead of ~12 eager ones behind every decode step
             self._commit_kernel(ids, didx, self.last_ids, self.occurrence, self.penalty_weight, self.alpha_presence_vector,
-                                self.presence_penalty_tensor, status_out=status_out)
+                                self.presence_penalty_tensor, status_out=status_out, **({"lists": self._pen_lists} if self._pen_lists is not None else {}))
             return
         dl, il = didx.long(), ids.long()
         self.last_ids.index_copy_(0, dl, ids)
@@ -369,6 +372,8 @@ class Worker:
             s2[[slot]] = task.state[2].to(s2.device, non_blocking=True)
         self.occurrence[slot].zero_()
         self.alpha_presence_vector[slot].zero_()
+        if getattr(self, "_pen_lists", None) is not None:
+            self._pen_lists.reset(slot)
         self.temperature_tensor[slot, 0] = task.temperature if task.temperature > 0 else 1.0
         self.top_p_tensor[slot, 0] = task.top_p
         self.top_k_tensor[slot, 0] = task.top_k
@@ -453,7 +458,7 @@ class Worker:
             buf = torch.empty((nd + 1,), dtype=torch.int32, device=self.device)     # the ids, and the launch-status word behind them
             ids, status_out = buf[:nd], buf[nd:]
             self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
-                                  self.frequency_penalty_tensor.view(-1), didx, out=ids)
+                                  self.frequency_penalty_tensor.view(-1), didx, out=ids, **({"lists": self._pen_lists} if self._pen_lists is not None else {}))
         else:
             ids = self._penalize_argmax(logits, self.occurrence, self.alpha_presence_vector, self.penalty_decay_tensor.view(-1),
                                         self.frequency_penalty_tensor.view(-1), didx)

@@ -37,7 +37,8 @@ extern "C" {
  *      rwkv7_tmix_gemms_mm8, rwkv7_tmix_wkv7_fused_mm8, skinny_untile_weight, the clock probes)
  *   4  round 4: rwkv7_tmix_gemms / _mm8 gained `status` (a sticky status word of the caller's) ahead of spin_limit and the status
  *      word moved to the END of the sync words; rwkv7_commit_sampled gained status_src / status_dst ahead of `stream`;
- *      new: mm8t_seq_exact, mm8t_exact_workspace_bytes, mm8_dequant_f16, chirrup_device_cu_count */
+ *      new: mm8t_seq_exact, mm8t_exact_workspace_bytes, mm8_dequant_f16, chirrup_device_cu_count, rwkv7_penalize_argmax_listed,
+ *      rwkv7_commit_sampled_listed */
 #define CHIRRUP_ABI_VERSION 4
 int chirrup_abi_version(void);
 const char *chirrup_target_arch(void);
@@ -434,6 +435,21 @@ int rwkv7_penalize_argmax(int B, int V, void *logits, float *occurrence, const f
 int rwkv7_commit_sampled(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
                          const float *penalty_weight, float *alpha_presence, const float *presence, int64_t presence_stride,
                          const int32_t *status_src, int32_t *status_dst, void *stream);
+/* The penalty step without the dense pass over the tables (round 4).  A slot's occurrence / alpha_presence rows are zero except at
+ * the ids it has sampled, so beside the (unchanged, dense, exact) tables every slot keeps the list of those ids: pen_list int32
+ * [n_slots][cap], pen_count int32 [n_slots] (entries used; -1 = more than cap distinct ids: the slot takes the dense pass until it
+ * is reset), pen_bits uint32 [n_slots][V / 32] (an id is listed once).  rwkv7_commit_sampled_listed = rwkv7_commit_sampled + the
+ * list update; rwkv7_penalize_argmax_listed = rwkv7_penalize_argmax touching only the listed entries -- per element the same
+ * arithmetic, which is the identity on entries that are zero: logits, occurrence and ids are bit-identical to the dense entry
+ * points'.  Resetting a slot: zero its two table rows (or their listed entries), its pen_bits row and pen_count[slot].  The rows
+ * of ONE commit launch must address distinct slots.  V % 32 == 0. */
+int rwkv7_penalize_argmax_listed(int B, int V, void *logits, float *occurrence, const float *alpha_presence, const void *penalty_decay,
+                                 const void *frequency_penalty, const int32_t *slot_idx, int32_t *ids, const int32_t *pen_list,
+                                 const int32_t *pen_count, int cap, void *stream);
+int rwkv7_commit_sampled_listed(int n, int V, const int32_t *ids, const int32_t *slot_idx, int32_t *last_ids, float *occurrence,
+                                const float *penalty_weight, float *alpha_presence, const float *presence, int64_t presence_stride,
+                                const int32_t *status_src, int32_t *status_dst, int32_t *pen_list, int32_t *pen_count,
+                                uint32_t *pen_bits, int cap, void *stream);
 
 /* The two ends of a decode step around the layers (Albatross/rwkv7.py:503-517 `_pre`: the embedding gather; :561-563 `_post`:
  * state[2] += T), each one launch.  rwkv7_embed_rows: x[b][t] = emb[token], token = tokens[b*T + t], or -- when that is negative and

@@ -217,3 +217,58 @@ def test_measured_gemm_formulation_of_a_prefill_chunk_changes_no_result_beyond_s
     m._mm_plan = {}
     m.forward_seq_batch_seperate(toks, m.generate_zero_state(B))
     assert m._mm_plan == {}
+
+
+@pytest.mark.parametrize("cap", [4096, 6])
+def test_listed_penalty_step_is_bit_identical_to_the_dense_pass(cap):
+    """ops.PenaltyLists: the penalty step over a slot's LIST of sampled ids (rwkv7_penalize_argmax_listed / _commit_sampled_listed)
+    against the dense pass over its 65 536-wide table rows (rwkv7_penalize_argmax / _commit_sampled, whose arithmetic the reference
+    fixture pins: tests/test_worker_gpu.py) -- 40 steps of a 7-row batch over a 12-slot pool with real penalties, repeated ids,
+    no-penalty ids, a slot recycled half way and (cap = 6) slots that overflow their list and fall back to the dense pass: logits,
+    both tables, last ids and sampled ids equal bit for bit at every step."""
+    from chirrup_amd import ops
+
+    dev = torch.device("cuda", 0)
+    n_slots, B, V = 12, 7, 4096
+    g = torch.Generator(device=dev).manual_seed(3)
+    slots = torch.tensor([9, 0, 4, 11, 2, 7, 5], dtype=torch.int32, device=dev)
+    decay = (torch.rand(n_slots, generator=g, device=dev) * 0.1 + 0.9).half()
+    freq = (torch.rand(n_slots, generator=g, device=dev)).half()
+    presence = torch.rand((n_slots, 1), generator=g, device=dev)
+    pw = torch.ones(V, device=dev)
+    pw[[33, 10, 49]] = 0.0
+
+    def fresh():
+        return dict(occ=torch.zeros((n_slots, V), device=dev), alpha=torch.zeros((n_slots, V), device=dev),
+                    last=torch.zeros(n_slots, dtype=torch.int32, device=dev))
+
+    d, l = fresh(), fresh()
+    lists = ops.PenaltyLists(n_slots, V, dev, cap=cap)
+    for step in range(40):
+        lg = (torch.randn((B, V), generator=g, device=dev) * 2).half()
+        hot = torch.randint(0, 12, (B,), generator=g, device=dev)                 # few distinct winners: ids repeat, incl. the no-penalty 10
+        lg[torch.arange(B, device=dev), hot * 3 + 1] += 9.0
+        lg_d, lg_l = lg.clone(), lg.clone()
+        ids_d = ops.penalize_argmax(lg_d, d["occ"], d["alpha"], decay, freq, slots)
+        ids_l = ops.penalize_argmax(lg_l, l["occ"], l["alpha"], decay, freq, slots, lists=lists)
+        assert torch.equal(ids_d, ids_l), step
+        assert torch.equal(lg_d.view(torch.int16), lg_l.view(torch.int16)), step
+        ops.commit_sampled(ids_d, slots, d["last"], d["occ"], pw, d["alpha"], presence)
+        ops.commit_sampled(ids_l, slots, l["last"], l["occ"], pw, l["alpha"], presence, lists=lists)
+        for k in ("occ", "alpha", "last"):
+            assert torch.equal(d[k], l[k]), (step, k)
+        if step == 20:                                                            # slot 4 is recycled: rows zeroed, list reset
+            for t in (d, l):
+                t["occ"][4].zero_(), t["alpha"][4].zero_()
+            lists.reset(4)
+    counts = lists.count.cpu().tolist()
+    used = slots.cpu().tolist()
+    if cap == 6:
+        assert any(counts[s] == -1 for s in used)                                 # some slots overflowed and ran the dense pass
+    else:
+        assert all(0 < counts[s] <= 40 for s in used) and all(counts[s] == 0 for s in range(n_slots) if s not in used)
+        for s in used:                                                            # the list = the distinct ids the slot sampled since its reset
+            ids = lists.ids[s, :counts[s]].cpu().tolist()
+            assert len(set(ids)) == len(ids)
+            live = set(torch.nonzero((l["occ"][s] != 0) | (l["alpha"][s] != 0)).view(-1).cpu().tolist())
+            assert live <= set(ids)                                               # every entry that can be non-zero is listed
