@@ -272,3 +272,34 @@ def test_listed_penalty_step_is_bit_identical_to_the_dense_pass(cap):
             assert len(set(ids)) == len(ids)
             live = set(torch.nonzero((l["occ"][s] != 0) | (l["alpha"][s] != 0)).view(-1).cpu().tolist())
             assert live <= set(ids)                                               # every entry that can be non-zero is listed
+
+
+def test_listed_penalty_step_at_the_bench_shape():
+    """... and at BASELINE's shape (200 rows over 201 slots, V = 65 536), six steps with the reference's default penalties: the listed
+    step's ids, logits and both tables equal the dense pass's bit for bit."""
+    from chirrup_amd import ops
+
+    dev = torch.device("cuda", 0)
+    n_slots, B, V = 201, 200, 65536
+    g = torch.Generator(device=dev).manual_seed(8)
+    slots = torch.randperm(n_slots, generator=g, device=dev)[:B].to(torch.int32)
+    decay = torch.full((n_slots,), 0.996, dtype=torch.float16, device=dev)
+    freq = torch.full((n_slots,), 0.5, dtype=torch.float16, device=dev)
+    presence = torch.full((n_slots, 1), 0.5, device=dev)
+    pw = torch.ones(V, device=dev)
+    pw[[33, 10, 49, 50, 51]] = 0.0
+    tabs = [dict(occ=torch.zeros((n_slots, V), device=dev), alpha=torch.zeros((n_slots, V), device=dev),
+                 last=torch.zeros(n_slots, dtype=torch.int32, device=dev)) for _ in range(2)]
+    lists = ops.PenaltyLists(n_slots, V, dev)
+    for step in range(6):
+        lg = (torch.randn((B, V), generator=g, device=dev) * 2).half()
+        lg[:, 10] += 4.0 if step % 2 else 0.0                                     # a no-penalty id wins every other step
+        a, b = lg.clone(), lg.clone()
+        ids_d = ops.penalize_argmax(a, tabs[0]["occ"], tabs[0]["alpha"], decay, freq, slots)
+        ids_l = ops.penalize_argmax(b, tabs[1]["occ"], tabs[1]["alpha"], decay, freq, slots, lists=lists)
+        assert torch.equal(ids_d, ids_l) and torch.equal(a.view(torch.int16), b.view(torch.int16)), step
+        ops.commit_sampled(ids_d, slots, tabs[0]["last"], tabs[0]["occ"], pw, tabs[0]["alpha"], presence)
+        ops.commit_sampled(ids_l, slots, tabs[1]["last"], tabs[1]["occ"], pw, tabs[1]["alpha"], presence, lists=lists)
+        for k in ("occ", "alpha", "last"):
+            assert torch.equal(tabs[0][k], tabs[1][k]), (step, k)
+    assert int(lists.count.max()) <= 6 and int(lists.count[slots.long()].min()) >= 1
